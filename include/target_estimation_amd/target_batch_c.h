@@ -1,0 +1,111 @@
+/*
+ * target_batch_c.h -- batched extension of the target_manager C boundary (not in the reference).
+ *
+ * The reference steps one target per call under a manager-wide mutex
+ * (src/target_manager.cpp:190-225).  At 10^4..10^6 targets the per-id calls cannot be the fast
+ * path, so this header adds (a) array-of-ids entry points with host buffers and (b) a
+ * device-resident dense path whose inputs already live in HBM (no host staging; this is what
+ * bench.py times and what a multi-GPU caller uses, one manager per rank).
+ *
+ * Plain C ABI: pointers and sizes only.  "dev" pointers are HIP device pointers (e.g.
+ * torch.Tensor.data_ptr()).  Unless stated, functions return 0 on success and a negative
+ * error code (message on stderr) on failure; they never throw.
+ */
+#ifndef TARGET_ESTIMATION_AMD_TARGET_BATCH_C_H
+#define TARGET_ESTIMATION_AMD_TARGET_BATCH_C_H
+
+#include "target_manager_c.h"
+
+typedef void target_batch_c; /* all targets of one (model, Q, R) inside a manager */
+
+/* model ids = the reference enum TargetManager::target_t (target_manager.hpp:38) */
+#define TARGET_ANGULAR_RATES 0
+#define TARGET_ANGULAR_VELOCITIES 1
+#define TARGET_UNIFORM_ACCELERATION 2
+#define TARGET_UNIFORM_VELOCITY 3
+#define TARGET_DTYPE_F64 0
+#define TARGET_DTYPE_F32 1
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- construction ---------------------------------------------------------------------- */
+/* file may be NULL (no default model: use the *_typed initialisers, as the reference's
+ * default-constructed TargetManager, target_manager.cpp:106-109).  dtype: TARGET_DTYPE_*.
+ * lanes_per_target: 0 = the tuned default for (model, dtype); otherwise 1, 2, 3 or 6. */
+target_manager_c* target_manager_new_ex(const char* file, int dtype, int lanes_per_target);
+/* all launches of this manager go to `hip_stream` (a hipStream_t; NULL = default stream) */
+int target_manager_set_stream(target_manager_c* self, void* hip_stream);
+int target_manager_synchronize(target_manager_c* self);
+const char* target_manager_last_error(void);
+
+/* TargetManager::init(type,id,dt0,t0,Q,R,P0,p0,v0,a0), target_manager.hpp:85-87.
+ * Q, P0: n*n row-major; R: m*m; v0, a0 may be NULL (zeros). */
+int target_manager_init_typed(target_manager_c* self, int type, unsigned int id, double dt0, double t0,
+                              const double* Q, const double* R, const double* P0, const double* p0,
+                              const double* v0, const double* a0);
+/* n targets at once with the manager's default model; p0 [n][7], v0/a0 [n][6] or NULL.
+ * Existing ids are skipped.  Returns the number created (or < 0). */
+long target_manager_init_batch(target_manager_c* self, const unsigned int* ids, long n, double dt0, double t0,
+                               const double* p0, const double* v0, const double* a0);
+long target_manager_init_batch_typed(target_manager_c* self, int type, const unsigned int* ids, long n, double dt0,
+                                     double t0, const double* Q, const double* R, const double* P0,
+                                     int per_target_P0, const double* p0, const double* v0, const double* a0);
+/* TargetManager::erase, target_manager.cpp:227-241.  1 = erased, 0 = unknown id. */
+int target_manager_erase(target_manager_c* self, unsigned int id);
+long target_manager_size(target_manager_c* self);
+/* TargetManager::getAvailableTargets (ascending ids), target_manager.cpp:126-133 */
+long target_manager_get_available_targets(target_manager_c* self, unsigned int* ids_out, long capacity);
+
+/* ---- array-of-ids calls, host buffers ---------------------------------------------------- */
+/* for i < n: has_meas[i] ? update(ids[i], dt, meas[i]) : update(ids[i], dt); meas [n][7] may be
+ * NULL (predict only), has_meas may be NULL (all measured).  ids must be distinct.
+ * Returns the number of known ids stepped. */
+long target_manager_update_meas_batch(target_manager_c* self, const unsigned int* ids, long n, double dt,
+                                      const double* meas, const unsigned char* has_meas);
+/* TargetManager::update(dt): predict every target, target_manager.cpp:220-225 */
+int target_manager_update_all(target_manager_c* self, double dt);
+/* any of pose [n][7], twist [n][6], acceleration [n][6], found [n] may be NULL */
+long target_manager_get_est_batch(target_manager_c* self, const unsigned int* ids, long n, double* pose,
+                                  double* twist, double* acceleration, unsigned char* found);
+/* TargetInterface::getEstimatedPose(t1) / Twist(t1) / Acceleration(t1) (src/types, target_interface.cpp:123-140) */
+long target_manager_get_est_at_batch(target_manager_c* self, const unsigned int* ids, long n, double t1,
+                                     double* pose, double* twist, double* acceleration, unsigned char* found);
+/* getTarget(id)->getEstimator()->getState()/getP() for ids of ONE model: x [n][ns], P [n][ns*ns]
+ * row-major.  Returns the state size ns, or < 0. */
+long target_manager_get_state_batch(target_manager_c* self, const unsigned int* ids, long n, double* x, double* P);
+/* TargetInterface::getTime() */
+int target_manager_get_time(target_manager_c* self, unsigned int id, double* t);
+
+/* ---- device-resident dense path ---------------------------------------------------------- */
+int target_manager_num_batches(target_manager_c* self);
+target_batch_c* target_manager_get_batch(target_manager_c* self, int index);
+target_batch_c* target_manager_get_batch_of_type(target_manager_c* self, int type);
+long target_batch_size(target_batch_c* b);
+int target_batch_type(target_batch_c* b);
+int target_batch_dtype(target_batch_c* b);
+int target_batch_state_dim(target_batch_c* b);
+int target_batch_meas_dim(target_batch_c* b);
+int target_batch_lanes_per_target(target_batch_c* b);
+/* bytes one predict+update cycle of one target must move ((2n + 2n^2 + 7 (+6)) * w) */
+long target_batch_algorithmic_bytes(target_batch_c* b);
+/* HBM bytes actually allocated per target (record incl. tile padding) */
+double target_batch_resident_bytes_per_target(target_batch_c* b);
+/* slot -> id of the dense order (slot i is row i of every dense array) */
+long target_batch_slot_ids(target_batch_c* b, unsigned int* ids_out, long capacity);
+/* One predict(+update) tick over every target of the batch, asynchronous on the manager's stream.
+ *   meas_dev    : SoA [7][ld] in the batch precision (row c = component c of [x y z qx qy qz qw]
+ *                 for all slots), or NULL for predict-only.  Linear models read rows 0..2 only.
+ *   has_meas_dev: per-slot bytes, or NULL (every slot has a measurement). */
+int target_batch_step(target_batch_c* b, double dt, const void* meas_dev, long ld, const unsigned char* has_meas_dev);
+/* derived outputs of every slot into device arrays of doubles ([size][7], [size][6], [size][6];
+ * any may be NULL); at_time != 0 extrapolates to t1 */
+int target_batch_get_est_dev(target_batch_c* b, double* pose_dev, double* twist_dev, double* acc_dev, int at_time, double t1);
+/* AoS doubles [n][7] (host layout of the reference) -> SoA [7][ld] in the batch precision, on device */
+int target_batch_pack_meas_dev(target_batch_c* b, const double* meas_aos_dev, long n, void* meas_soa_dev, long ld);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,97 @@
+"""ctypes binding of libtarget_estimation_amd.so (the C ABI in include/target_estimation_amd/).
+
+There is no fallback: if the HIP library has not been built, importing the handle raises.
+"""
+import ctypes as C
+import os
+
+from ._build import LIB
+
+_lib = None
+
+c_uint_p = C.POINTER(C.c_uint)
+c_double_p = C.POINTER(C.c_double)
+c_ubyte_p = C.POINTER(C.c_ubyte)
+
+# every symbol include/target_estimation_amd/*.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    # target_manager_c.h (the reference's ten symbols)
+    "target_manager_new": (C.c_void_p, [C.c_char_p]),
+    "target_manager_init": (None, [C.c_void_p, C.c_uint, C.c_double, c_double_p, C.c_double]),
+    "target_manager_update_meas": (None, [C.c_void_p, C.c_uint, C.c_double, c_double_p]),
+    "target_manager_update": (None, [C.c_void_p, C.c_uint, C.c_double]),
+    "target_manager_get_est_pose": (C.c_bool, [C.c_void_p, C.c_uint, c_double_p]),
+    "target_manager_get_est_twist": (C.c_bool, [C.c_void_p, C.c_uint, c_double_p]),
+    "target_manager_get_est_acceleration": (C.c_bool, [C.c_void_p, C.c_uint, c_double_p]),
+    "target_manager_get_n_measurements": (C.c_int, [C.c_void_p, C.c_uint]),
+    "target_manager_log": (None, [C.c_void_p]),
+    "target_manager_delete": (None, [C.c_void_p]),
+    # target_batch_c.h
+    "target_manager_new_ex": (C.c_void_p, [C.c_char_p, C.c_int, C.c_int]),
+    "target_manager_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "target_manager_synchronize": (C.c_int, [C.c_void_p]),
+    "target_manager_last_error": (C.c_char_p, []),
+    "target_manager_init_typed": (C.c_int, [C.c_void_p, C.c_int, C.c_uint, C.c_double, C.c_double, c_double_p,
+                                            c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
+    "target_manager_init_batch": (C.c_long, [C.c_void_p, c_uint_p, C.c_long, C.c_double, C.c_double, c_double_p,
+                                             c_double_p, c_double_p]),
+    "target_manager_init_batch_typed": (C.c_long, [C.c_void_p, C.c_int, c_uint_p, C.c_long, C.c_double, C.c_double,
+                                                   c_double_p, c_double_p, c_double_p, C.c_int, c_double_p,
+                                                   c_double_p, c_double_p]),
+    "target_manager_erase": (C.c_int, [C.c_void_p, C.c_uint]),
+    "target_manager_size": (C.c_long, [C.c_void_p]),
+    "target_manager_get_available_targets": (C.c_long, [C.c_void_p, c_uint_p, C.c_long]),
+    "target_manager_update_meas_batch": (C.c_long, [C.c_void_p, c_uint_p, C.c_long, C.c_double, c_double_p, c_ubyte_p]),
+    "target_manager_update_all": (C.c_int, [C.c_void_p, C.c_double]),
+    "target_manager_get_est_batch": (C.c_long, [C.c_void_p, c_uint_p, C.c_long, c_double_p, c_double_p, c_double_p, c_ubyte_p]),
+    "target_manager_get_est_at_batch": (C.c_long, [C.c_void_p, c_uint_p, C.c_long, C.c_double, c_double_p, c_double_p,
+                                                   c_double_p, c_ubyte_p]),
+    "target_manager_get_state_batch": (C.c_long, [C.c_void_p, c_uint_p, C.c_long, c_double_p, c_double_p]),
+    "target_manager_get_time": (C.c_int, [C.c_void_p, C.c_uint, c_double_p]),
+    "target_manager_num_batches": (C.c_int, [C.c_void_p]),
+    "target_manager_get_batch": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "target_manager_get_batch_of_type": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "target_batch_size": (C.c_long, [C.c_void_p]),
+    "target_batch_type": (C.c_int, [C.c_void_p]),
+    "target_batch_dtype": (C.c_int, [C.c_void_p]),
+    "target_batch_state_dim": (C.c_int, [C.c_void_p]),
+    "target_batch_meas_dim": (C.c_int, [C.c_void_p]),
+    "target_batch_lanes_per_target": (C.c_int, [C.c_void_p]),
+    "target_batch_algorithmic_bytes": (C.c_long, [C.c_void_p]),
+    "target_batch_resident_bytes_per_target": (C.c_double, [C.c_void_p]),
+    "target_batch_slot_ids": (C.c_long, [C.c_void_p, c_uint_p, C.c_long]),
+    "target_batch_step": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_long, C.c_void_p]),
+    "target_batch_get_est_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double]),
+    "target_batch_pack_meas_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_long]),
+}
+
+
+def lib():
+    """The loaded shared library; raises (loudly) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        raise RuntimeError(
+            "target_estimation_amd: %s is missing. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+            "There is no CPU fallback." % LIB)
+    # One HIP runtime per process: torch wheels bundle their own libamdhip64.so (SONAME
+    # libamdhip64.so.7, the same as /opt/rocm's).  If torch is imported first, the dynamic loader
+    # resolves this library's DT_NEEDED against the copy already mapped; loaded the other way round
+    # the process ends up with two runtimes and the second one finds no device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    handle = C.CDLL(LIB)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = handle
+    return _lib
+
+
+def last_error():
+    return lib().target_manager_last_error().decode()

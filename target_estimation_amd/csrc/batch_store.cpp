@@ -1,0 +1,300 @@
+// batch_store.cpp -- see batch_store.hpp.
+#include "batch_store.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+#include "hip_check.hpp"
+
+namespace te {
+
+const Ops* get_ops(int type, int dtype, int g) {
+  switch (type) {
+    case UNIFORM_VELOCITY: return get_ops_uv(dtype, g);
+    case UNIFORM_ACCELERATION: return get_ops_ua(dtype, g);
+    case ANGULAR_RATES: return get_ops_ar(dtype, g);
+    case ANGULAR_VELOCITIES: return get_ops_av(dtype, g);
+    default: return nullptr;
+  }
+}
+
+Batch::Batch(int type, int dtype, int lanes, const double* Q, const double* R, hipStream_t stream)
+    : type_(type), dtype_(dtype), ops_(get_ops(type, dtype, lanes)), stream_(stream) {
+  if (!ops_) throw std::runtime_error("target_estimation_amd: unsupported (model, precision, lanes-per-target) combination");
+  const int n = ops_->L.n, m = ops_->L.m;
+  Q_.assign(Q, Q + n * n);
+  R_.assign(R, R + m * m);
+  const size_t es = elem_size();
+  std::vector<unsigned char> host((size_t)(n * n + m * m) * es);
+  for (int i = 0; i < n * n + m * m; ++i) {
+    const double v = i < n * n ? Q_[i] : R_[i - n * n];
+    if (dtype_ == F64) reinterpret_cast<double*>(host.data())[i] = v;
+    else reinterpret_cast<float*>(host.data())[i] = (float)v;
+  }
+  TE_HIP_CHECK(hipMalloc(&d_qr_, host.size()));
+  TE_HIP_CHECK(hipMemcpy(d_qr_, host.data(), host.size(), hipMemcpyHostToDevice));
+  TE_HIP_CHECK(hipHostMalloc((void**)&h_ring_idx_, sizeof(int) * kRing, hipHostMallocMapped));
+  TE_HIP_CHECK(hipHostMalloc((void**)&h_ring_meas_, sizeof(double) * 8 * kRing, hipHostMallocMapped));
+  TE_HIP_CHECK(hipHostMalloc((void**)&h_ring_out_, sizeof(double) * 32, hipHostMallocMapped));
+}
+
+Batch::~Batch() {
+  (void)hipStreamSynchronize(stream_);
+  (void)hipFree(d_qr_); (void)hipFree(d_rec_); (void)hipFree(d_tbase_); (void)hipFree(d_nmbase_);
+  (void)hipFree(d_idx_); (void)hipFree(d_aos_); (void)hipFree(d_meas_); (void)hipFree(d_mask_); (void)hipFree(d_P0_);
+  (void)hipHostFree(h_ring_idx_); (void)hipHostFree(h_ring_meas_); (void)hipHostFree(h_ring_out_);
+}
+
+bool Batch::same_params(int type, const double* Q, const double* R) const {
+  if (type != type_) return false;
+  return std::memcmp(Q, Q_.data(), Q_.size() * sizeof(double)) == 0 &&
+         std::memcmp(R, R_.data(), R_.size() * sizeof(double)) == 0;
+}
+
+void Batch::synchronize() { TE_HIP_CHECK(hipStreamSynchronize(stream_)); }
+
+long Batch::algorithmic_bytes_per_cycle() const {
+  const long n = ops_->L.n;
+  const bool angular = (type_ == ANGULAR_RATES || type_ == ANGULAR_VELOCITIES);
+  return (2 * n + 2 * n * n + 7 + (angular ? 6 : 0)) * (long)elem_size();
+}
+
+void Batch::reserve(long n) {
+  if (n <= cap_) return;
+  const long tpw = ops_->L.tpw;
+  long want = std::max(n, cap_ * 2);
+  want = (want + tpw - 1) / tpw * tpw;
+  const size_t new_bytes = (size_t)(want / tpw) * (size_t)ops_->L.tile_bytes;
+  char* rec = nullptr;
+  double* tb = nullptr;
+  int* nm = nullptr;
+  TE_HIP_CHECK(hipMalloc((void**)&rec, new_bytes));
+  TE_HIP_CHECK(hipMalloc((void**)&tb, sizeof(double) * want));
+  TE_HIP_CHECK(hipMalloc((void**)&nm, sizeof(int) * want));
+  TE_HIP_CHECK(hipMemsetAsync(rec, 0, new_bytes, stream_));
+  TE_HIP_CHECK(hipMemsetAsync(tb, 0, sizeof(double) * want, stream_));
+  TE_HIP_CHECK(hipMemsetAsync(nm, 0, sizeof(int) * want, stream_));
+  if (cap_ > 0) {
+    TE_HIP_CHECK(hipMemcpyAsync(rec, d_rec_, (size_t)(cap_ / tpw) * (size_t)ops_->L.tile_bytes, hipMemcpyDeviceToDevice, stream_));
+    TE_HIP_CHECK(hipMemcpyAsync(tb, d_tbase_, sizeof(double) * cap_, hipMemcpyDeviceToDevice, stream_));
+    TE_HIP_CHECK(hipMemcpyAsync(nm, d_nmbase_, sizeof(int) * cap_, hipMemcpyDeviceToDevice, stream_));
+  }
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));
+  (void)hipFree(d_rec_); (void)hipFree(d_tbase_); (void)hipFree(d_nmbase_);
+  d_rec_ = rec; d_tbase_ = tb; d_nmbase_ = nm; cap_ = want;
+}
+
+void Batch::stage_reserve(long n) {
+  if (n <= stage_cap_) return;
+  const long want = std::max(n, stage_cap_ * 2);
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));
+  (void)hipFree(d_idx_); (void)hipFree(d_aos_); (void)hipFree(d_meas_); (void)hipFree(d_mask_);
+  TE_HIP_CHECK(hipMalloc((void**)&d_idx_, sizeof(int) * want));
+  TE_HIP_CHECK(hipMalloc((void**)&d_aos_, sizeof(double) * 19 * want));
+  TE_HIP_CHECK(hipMalloc((void**)&d_meas_, elem_size() * 7 * want));
+  TE_HIP_CHECK(hipMalloc((void**)&d_mask_, (size_t)want));
+  stage_cap_ = want;
+}
+
+void Batch::upload_slots(const int* slots, long n) {
+  TE_HIP_CHECK(hipMemcpyAsync(d_idx_, slots, sizeof(int) * n, hipMemcpyHostToDevice, stream_));
+}
+
+long Batch::append(long count, const unsigned* ids, double t0, const double* P0, bool per_target_P0,
+                   const double* p0, const double* v0, const double* a0) {
+  if (count <= 0) return n_;
+  const long first = n_;
+  const int N = ops_->L.n;
+  reserve(n_ + count);
+  stage_reserve(count);
+  std::vector<int> slots((size_t)count);
+  for (long i = 0; i < count; ++i) slots[(size_t)i] = (int)(first + i);
+  upload_slots(slots.data(), count);
+  double* d_p0 = d_aos_;
+  double* d_v0 = d_aos_ + 7 * count;
+  double* d_a0 = d_aos_ + 13 * count;
+  TE_HIP_CHECK(hipMemcpyAsync(d_p0, p0, sizeof(double) * 7 * count, hipMemcpyHostToDevice, stream_));
+  if (v0) TE_HIP_CHECK(hipMemcpyAsync(d_v0, v0, sizeof(double) * 6 * count, hipMemcpyHostToDevice, stream_));
+  if (a0) TE_HIP_CHECK(hipMemcpyAsync(d_a0, a0, sizeof(double) * 6 * count, hipMemcpyHostToDevice, stream_));
+  const long p0_words = (per_target_P0 ? count : 1) * (long)N * N;
+  if (p0_words > P0_cap_) {
+    TE_HIP_CHECK(hipStreamSynchronize(stream_));
+    (void)hipFree(d_P0_);
+    TE_HIP_CHECK(hipMalloc((void**)&d_P0_, sizeof(double) * p0_words));
+    P0_cap_ = p0_words;
+  }
+  TE_HIP_CHECK(hipMemcpyAsync(d_P0_, P0, sizeof(double) * p0_words, hipMemcpyHostToDevice, stream_));
+  InitArgs a;
+  a.rec = d_rec_; a.idx = d_idx_; a.n = count; a.p0 = d_p0; a.v0 = v0 ? d_v0 : nullptr; a.a0 = a0 ? d_a0 : nullptr;
+  a.P0 = d_P0_; a.per_target_P0 = per_target_P0 ? 1 : 0;
+  a.t_off = t0 - t_acc_; a.nm_off = (int)(-nm_acc_);
+  a.t_base = d_tbase_; a.nm_base = d_nmbase_;
+  ops_->init(a, stream_);
+  TE_HIP_CHECK(hipGetLastError());
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));  // host staging arrays may be pageable
+  slot_ids_.insert(slot_ids_.end(), ids, ids + count);
+  n_ += count;
+  return first;
+}
+
+unsigned Batch::erase_slot(long slot) {
+  const long last = n_ - 1;
+  unsigned moved = slot_ids_[(size_t)slot];
+  if (slot != last) {
+    ops_->move_record(d_rec_, last, slot, d_tbase_, d_nmbase_, stream_);
+    TE_HIP_CHECK(hipGetLastError());
+    moved = slot_ids_[(size_t)last];
+    slot_ids_[(size_t)slot] = moved;
+  }
+  slot_ids_.pop_back();
+  n_ = last;
+  return moved;
+}
+
+void Batch::step_dense(double dt, const void* meas_dev, long ld, const unsigned char* has_dev) {
+  if (n_ == 0) return;
+  StepParams p;
+  p.rec = d_rec_; p.qr = d_qr_; p.n = n_; p.idx = nullptr; p.meas = meas_dev; p.meas_ld = ld;
+  p.has_meas = has_dev; p.dt_per = nullptr; p.dt = dt; p.t_base = d_tbase_; p.nm_base = d_nmbase_;
+  ops_->step(p, stream_);
+  t_acc_ += dt;
+  if (meas_dev && !has_dev) nm_acc_ += 1;
+}
+
+void Batch::step_indexed(const int* slots, long n, double dt, const double* meas_aos, const unsigned char* has) {
+  if (n <= 0) return;
+  stage_reserve(n);
+  upload_slots(slots, n);
+  if (meas_aos) {
+    TE_HIP_CHECK(hipMemcpyAsync(d_aos_, meas_aos, sizeof(double) * 7 * n, hipMemcpyHostToDevice, stream_));
+    ops_->pack_meas(d_aos_, n, d_meas_, n, stream_);
+  }
+  if (has) TE_HIP_CHECK(hipMemcpyAsync(d_mask_, has, (size_t)n, hipMemcpyHostToDevice, stream_));
+  StepParams p;
+  p.rec = d_rec_; p.qr = d_qr_; p.n = n; p.idx = d_idx_; p.meas = meas_aos ? d_meas_ : nullptr; p.meas_ld = n;
+  p.has_meas = (meas_aos && has) ? d_mask_ : nullptr; p.dt_per = nullptr; p.dt = dt;
+  p.t_base = d_tbase_; p.nm_base = d_nmbase_;
+  ops_->step(p, stream_);
+  TE_HIP_CHECK(hipGetLastError());
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));  // caller's host arrays may be reused after return
+}
+
+void Batch::step_one(long slot, double dt, const double* meas7) {
+  // one-target call of the reference C ABI: inputs go through a pinned, device-visible ring so
+  // the launch is asynchronous and needs no staging copy
+  if (ring_head_ == kRing) {
+    TE_HIP_CHECK(hipStreamSynchronize(stream_));
+    ring_head_ = 0;
+  }
+  const int k = ring_head_++;
+  h_ring_idx_[k] = (int)slot;
+  void* mslot = h_ring_meas_ + 8 * k;
+  if (meas7) {
+    if (dtype_ == F64) for (int c = 0; c < 7; ++c) static_cast<double*>(mslot)[c] = meas7[c];
+    else for (int c = 0; c < 7; ++c) static_cast<float*>(mslot)[c] = (float)meas7[c];
+  }
+  StepParams p;
+  p.rec = d_rec_; p.qr = d_qr_; p.n = 1; p.idx = h_ring_idx_ + k; p.meas = meas7 ? mslot : nullptr; p.meas_ld = 1;
+  p.has_meas = nullptr; p.dt_per = nullptr; p.dt = dt; p.t_base = d_tbase_; p.nm_base = d_nmbase_;
+  ops_->step(p, stream_);
+  TE_HIP_CHECK(hipGetLastError());
+}
+
+void Batch::outputs(const int* slots, long n, double* pose, double* twist, double* acc, bool at_time, double t1) {
+  if (n <= 0) return;
+  stage_reserve(n);
+  if (slots) upload_slots(slots, n);
+  OutArgs a;
+  a.rec = d_rec_; a.idx = slots ? d_idx_ : nullptr; a.n = n;
+  a.pose = pose ? d_aos_ : nullptr; a.twist = twist ? d_aos_ + 7 * n : nullptr; a.acc = acc ? d_aos_ + 13 * n : nullptr;
+  a.at_time = at_time ? 1 : 0; a.t1 = t1; a.t_acc = t_acc_; a.t_base = d_tbase_;
+  ops_->outputs(a, stream_);
+  TE_HIP_CHECK(hipGetLastError());
+  if (pose) TE_HIP_CHECK(hipMemcpyAsync(pose, a.pose, sizeof(double) * 7 * n, hipMemcpyDeviceToHost, stream_));
+  if (twist) TE_HIP_CHECK(hipMemcpyAsync(twist, a.twist, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, stream_));
+  if (acc) TE_HIP_CHECK(hipMemcpyAsync(acc, a.acc, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, stream_));
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Batch::outputs_dev(double* pose_dev, double* twist_dev, double* acc_dev, bool at_time, double t1) {
+  if (n_ == 0) return;
+  OutArgs a;
+  a.rec = d_rec_; a.idx = nullptr; a.n = n_; a.pose = pose_dev; a.twist = twist_dev; a.acc = acc_dev;
+  a.at_time = at_time ? 1 : 0; a.t1 = t1; a.t_acc = t_acc_; a.t_base = d_tbase_;
+  ops_->outputs(a, stream_);
+  TE_HIP_CHECK(hipGetLastError());
+}
+
+void Batch::outputs_one(long slot, double* pose, double* twist, double* acc, bool at_time, double t1) {
+  // the ring entry must stay untouched until the kernel has run: synchronise before reuse
+  if (ring_head_ == kRing) {
+    TE_HIP_CHECK(hipStreamSynchronize(stream_));
+    ring_head_ = 0;
+  }
+  const int k = ring_head_++;
+  h_ring_idx_[k] = (int)slot;
+  OutArgs a;
+  a.rec = d_rec_; a.idx = h_ring_idx_ + k; a.n = 1;
+  a.pose = pose ? h_ring_out_ : nullptr; a.twist = twist ? h_ring_out_ + 7 : nullptr; a.acc = acc ? h_ring_out_ + 13 : nullptr;
+  a.at_time = at_time ? 1 : 0; a.t1 = t1; a.t_acc = t_acc_; a.t_base = d_tbase_;
+  ops_->outputs(a, stream_);
+  TE_HIP_CHECK(hipGetLastError());
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));
+  ring_head_ = 0;  // everything queued has completed
+  if (pose) std::memcpy(pose, h_ring_out_, sizeof(double) * 7);
+  if (twist) std::memcpy(twist, h_ring_out_ + 7, sizeof(double) * 6);
+  if (acc) std::memcpy(acc, h_ring_out_ + 13, sizeof(double) * 6);
+}
+
+void Batch::pack_meas_dev(const double* aos_dev, long n, void* soa_dev, long ld) {
+  ops_->pack_meas(aos_dev, n, soa_dev, ld, stream_);
+  TE_HIP_CHECK(hipGetLastError());
+}
+
+void Batch::get_state(const int* slots, long n, double* x, double* P) {
+  if (n <= 0) return;
+  const int N = ops_->L.n;
+  stage_reserve(n);
+  if (slots) upload_slots(slots, n);
+  double* dx = nullptr;
+  double* dP = nullptr;
+  if (x) TE_HIP_CHECK(hipMalloc((void**)&dx, sizeof(double) * N * n));
+  if (P) TE_HIP_CHECK(hipMalloc((void**)&dP, sizeof(double) * N * N * n));
+  ops_->get_state(d_rec_, slots ? d_idx_ : nullptr, n, dx, dP, stream_);
+  TE_HIP_CHECK(hipGetLastError());
+  if (x) TE_HIP_CHECK(hipMemcpyAsync(x, dx, sizeof(double) * N * n, hipMemcpyDeviceToHost, stream_));
+  if (P) TE_HIP_CHECK(hipMemcpyAsync(P, dP, sizeof(double) * N * N * n, hipMemcpyDeviceToHost, stream_));
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));
+  (void)hipFree(dx); (void)hipFree(dP);
+}
+
+void Batch::set_state(const int* slots, long n, const double* x, const double* P, const double* unwrap) {
+  if (n <= 0) return;
+  const int N = ops_->L.n;
+  stage_reserve(n);
+  if (slots) upload_slots(slots, n);
+  double *dx = nullptr, *dP = nullptr, *du = nullptr;
+  if (x) { TE_HIP_CHECK(hipMalloc((void**)&dx, sizeof(double) * N * n)); TE_HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * N * n, hipMemcpyHostToDevice, stream_)); }
+  if (P) { TE_HIP_CHECK(hipMalloc((void**)&dP, sizeof(double) * N * N * n)); TE_HIP_CHECK(hipMemcpyAsync(dP, P, sizeof(double) * N * N * n, hipMemcpyHostToDevice, stream_)); }
+  if (unwrap) { TE_HIP_CHECK(hipMalloc((void**)&du, sizeof(double) * 3 * n)); TE_HIP_CHECK(hipMemcpyAsync(du, unwrap, sizeof(double) * 3 * n, hipMemcpyHostToDevice, stream_)); }
+  ops_->set_state(d_rec_, slots ? d_idx_ : nullptr, n, dx, dP, du, stream_);
+  TE_HIP_CHECK(hipGetLastError());
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));
+  (void)hipFree(dx); (void)hipFree(dP); (void)hipFree(du);
+}
+
+long long Batch::n_measurements(long slot) {
+  int v = 0;
+  TE_HIP_CHECK(hipMemcpyAsync(&v, d_nmbase_ + slot, sizeof(int), hipMemcpyDeviceToHost, stream_));
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));
+  return (long long)v + nm_acc_;
+}
+
+double Batch::time(long slot) {
+  double v = 0;
+  TE_HIP_CHECK(hipMemcpyAsync(&v, d_tbase_ + slot, sizeof(double), hipMemcpyDeviceToHost, stream_));
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));
+  return v + t_acc_;
+}
+
+}  // namespace te

@@ -1,0 +1,105 @@
+// batch_store.hpp -- device-resident store of all targets of one motion model / parameter set /
+// precision, and the launches that act on it.  Replaces, for N targets at once, the per-target
+// objects of the reference (TargetInterface + its KalmanFilterInterface:
+// include/target_estimation/target_interface.hpp:193-282, kalman.hpp:95-150): instead of
+// (x, P, A, C, Q, R, P0, K, I) per target there is one shared (Q, R) and one lane record
+// (x, P, unwrap memory) per target in HBM (te_layout.hpp).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "kf_ops.hpp"
+
+namespace te {
+
+class Batch {
+ public:
+  Batch(int type, int dtype, int lanes, const double* Q, const double* R, hipStream_t stream);
+  ~Batch();
+  Batch(const Batch&) = delete;
+  Batch& operator=(const Batch&) = delete;
+
+  int type() const { return type_; }
+  int dtype() const { return dtype_; }
+  int n_state() const { return ops_->L.n; }
+  int n_meas() const { return ops_->L.m; }
+  const LayoutInfo& layout() const { return ops_->L; }
+  long size() const { return n_; }
+  size_t elem_size() const { return dtype_ == F64 ? 8 : 4; }
+  bool same_params(int type, const double* Q, const double* R) const;
+  void set_stream(hipStream_t s) { stream_ = s; }
+  hipStream_t stream() const { return stream_; }
+  unsigned slot_id(long slot) const { return slot_ids_[slot]; }
+  const std::vector<unsigned>& slot_ids() const { return slot_ids_; }
+  double clock() const { return t_acc_; }
+
+  // Construct `count` new targets in slots [size(), size()+count).  Host arrays.
+  long append(long count, const unsigned* ids, double t0, const double* P0, bool per_target_P0,
+              const double* p0, const double* v0, const double* a0);
+  // Remove a slot by moving the last slot into it; returns the id that now lives in `slot`
+  // (or the erased id if it was the last one).
+  unsigned erase_slot(long slot);
+
+  // One tick over every target, device-resident inputs (the fast path).
+  //   meas_dev: SoA [7][ld] in the batch precision, or null (predict only = TargetInterface::update)
+  //   has_dev : per-slot mask or null (all have a measurement)
+  void step_dense(double dt, const void* meas_dev, long ld, const unsigned char* has_dev);
+  // One tick over the listed slots, host inputs (meas rows follow the order of `slots`).
+  void step_indexed(const int* slots, long n, double dt, const double* meas_aos, const unsigned char* has);
+  void step_one(long slot, double dt, const double* meas7);
+
+  // Derived outputs to host arrays; slots == null means all slots in order.
+  void outputs(const int* slots, long n, double* pose, double* twist, double* acc, bool at_time, double t1);
+  // Dense, to device arrays [size()][7] / [size()][6] / [size()][6] (doubles).
+  void outputs_dev(double* pose_dev, double* twist_dev, double* acc_dev, bool at_time, double t1);
+  void outputs_one(long slot, double* pose, double* twist, double* acc, bool at_time, double t1);
+  // AoS doubles [n][7] on device -> SoA [7][ld] in the batch precision on device
+  void pack_meas_dev(const double* aos_dev, long n, void* soa_dev, long ld);
+
+  void get_state(const int* slots, long n, double* x, double* P);
+  void set_state(const int* slots, long n, const double* x, const double* P, const double* unwrap);
+  long long n_measurements(long slot);
+  double time(long slot);
+  void synchronize();
+
+  // bytes of HBM one predict+update cycle must move for one target (state read+write + the
+  // measurement words the model reads); used by the roofline accounting
+  long algorithmic_bytes_per_cycle() const;
+  char* records_dev() const { return d_rec_; }
+
+ private:
+  void reserve(long n);
+  void stage_reserve(long n);
+  void upload_slots(const int* slots, long n);
+
+  int type_, dtype_;
+  const Ops* ops_;
+  hipStream_t stream_;
+  std::vector<double> Q_, R_;
+  void* d_qr_ = nullptr;
+  char* d_rec_ = nullptr;
+  double* d_tbase_ = nullptr;
+  int* d_nmbase_ = nullptr;
+  long cap_ = 0;  // slots
+  long n_ = 0;
+  std::vector<unsigned> slot_ids_;
+  double t_acc_ = 0.0;      // batch clock: target time = t_base[slot] + t_acc_
+  long long nm_acc_ = 0;    // batch measurement counter
+  // staging for the host-array paths
+  long stage_cap_ = 0;
+  int* d_idx_ = nullptr;
+  double* d_aos_ = nullptr;        // [stage_cap][19] doubles: inputs (p0|v0|a0, meas) and outputs
+  void* d_meas_ = nullptr;         // SoA [7][stage_cap] in the batch precision
+  unsigned char* d_mask_ = nullptr;
+  double* d_P0_ = nullptr;
+  long P0_cap_ = 0;
+  // pinned, device-visible ring for the one-target calls of the reference's C ABI
+  static constexpr int kRing = 1024;
+  int ring_head_ = 0;
+  int* h_ring_idx_ = nullptr;
+  double* h_ring_meas_ = nullptr;  // kRing x 8 doubles of storage (T values packed at the front)
+  double* h_ring_out_ = nullptr;   // 19 doubles + time + count
+};
+
+}  // namespace te

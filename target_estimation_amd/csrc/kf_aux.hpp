@@ -1,0 +1,264 @@
+// kf_aux.hpp -- record access, target construction and output derivation kernels.
+// Not bandwidth-critical (one thread per target or per row); the step kernel is kf_step.hpp.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "te_device_math.hpp"
+#include "te_layout.hpp"
+
+namespace te {
+
+// pointer to element (r, c) of P (c < N) or to x[r] (c == N) of `slot`
+template <class C, typename T>
+__device__ __forceinline__ T* state_ptr(char* rec, long slot, int r, int c) {
+  const long tile = slot / C::TPW;
+  const int lane = (int)(slot % C::TPW) * C::G + (r % C::G);
+  const int q = (r % C::K) / C::G + (r / C::K) * C::KPL;
+  const int w = (c < C::N) ? q * C::N + c : C::X_OFF + q;
+  return reinterpret_cast<T*>(rec + tile * C::TILE_BYTES + record_word_offset<C, T>(lane, w));
+}
+// pointer to unwrap-memory component cc (0..2) of `slot`
+template <class C, typename T>
+__device__ __forceinline__ T* unwrap_ptr(char* rec, long slot, int cc) {
+  const int r = 3 + cc;
+  const long tile = slot / C::TPW;
+  const int lane = (int)(slot % C::TPW) * C::G + (r % C::G);
+  const int w = C::UW_OFF + cc / C::G;
+  return reinterpret_cast<T*>(rec + tile * C::TILE_BYTES + record_word_offset<C, T>(lane, w));
+}
+
+// geometry.hpp:619-628 pose7dToPose6d
+template <typename T> __device__ __forceinline__ void pose7_to_pose6(const T* p7, T* p6) {
+  T q[4] = {p7[3], p7[4], p7[5], p7[6]};
+  p6[0] = p7[0]; p6[1] = p7[1]; p6[2] = p7[2];
+  quat_normalize(q);
+  quat_to_rpy(q, p6 + 3);
+}
+
+struct InitArgs {
+  char* rec;
+  const int* idx;          // slot of entry e
+  long n;
+  const double* p0;        // [n][7]
+  const double* v0;        // [n][6] or null
+  const double* a0;        // [n][6] or null
+  const double* P0;        // [N*N] shared, or [n][N*N] when per_target_P0
+  int per_target_P0;
+  double t_off;            // t0 - batch clock
+  int nm_off;              // - batch measurement counter
+  double* t_base;
+  int* nm_base;
+};
+
+// Model constructors: uniform_velocity.cpp:50-56, uniform_acceleration.cpp:50-57,
+// angular_rates.cpp:57-65, angular_velocities.cpp:51-56,73 + KalmanFilterInterface::init
+// src/kalman.cpp:16-21 (x = x0, P = P0).  The unwrap memory starts at zero (the reference
+// leaves meas_rpy_internal_ uninitialised: angular_rates.hpp:110, angular_velocities.hpp:127).
+template <class M, typename T, int G>
+__global__ void init_kernel(const InitArgs a) {
+  using C = Cfg<M, T, G>;
+  constexpr int N = C::N;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.n) return;
+  const long slot = a.idx[e];
+  T p7[7], x0[N];
+#pragma unroll
+  for (int c = 0; c < 7; ++c) p7[c] = (T)a.p0[e * 7 + c];
+#pragma unroll
+  for (int r = 0; r < N; ++r) x0[r] = 0;
+  T v6[6], a6[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) { v6[c] = a.v0 ? (T)a.v0[e * 6 + c] : (T)0; a6[c] = a.a0 ? (T)a.a0[e * 6 + c] : (T)0; }
+  if constexpr (M::TYPE == UNIFORM_VELOCITY) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { x0[c] = p7[c]; x0[3 + c] = v6[c]; }
+  } else if constexpr (M::TYPE == UNIFORM_ACCELERATION) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { x0[c] = p7[c]; x0[3 + c] = v6[c]; x0[6 + c] = a6[c]; }
+  } else {
+    T p6[6];
+    pose7_to_pose6(p7, p6);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { x0[c] = p6[c]; x0[6 + c] = v6[c]; }
+    if constexpr (M::TYPE == ANGULAR_RATES) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) x0[12 + c] = a6[c];
+    }
+  }
+  const double* P0 = a.P0 + (a.per_target_P0 ? e * N * N : 0);
+  for (int r = 0; r < N; ++r) {
+    *state_ptr<C, T>(a.rec, slot, r, N) = x0[r];
+    for (int c = 0; c < N; ++c) *state_ptr<C, T>(a.rec, slot, r, c) = (T)P0[r * N + c];
+  }
+  if constexpr (M::ANGULAR) {
+    for (int cc = 0; cc < 3; ++cc) *unwrap_ptr<C, T>(a.rec, slot, cc) = 0;
+  }
+  a.t_base[slot] = a.t_off;
+  a.nm_base[slot] = a.nm_off;
+}
+
+// x [n][N] and P [n][N*N] (row-major, doubles) of the listed slots; one thread per (entry,row)
+template <class M, typename T, int G>
+__global__ void get_state_kernel(char* rec, const int* idx, long n, double* x_out, double* P_out) {
+  using C = Cfg<M, T, G>;
+  constexpr int N = C::N;
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n * N) return;
+  const long e = tid / N;
+  const int r = (int)(tid % N);
+  const long slot = idx ? (long)idx[e] : e;
+  if (x_out) x_out[e * N + r] = (double)*state_ptr<C, T>(rec, slot, r, N);
+  if (P_out)
+    for (int c = 0; c < N; ++c) P_out[(e * N + r) * N + c] = (double)*state_ptr<C, T>(rec, slot, r, c);
+}
+
+template <class M, typename T, int G>
+__global__ void set_state_kernel(char* rec, const int* idx, long n, const double* x_in, const double* P_in,
+                                 const double* uw_in) {
+  using C = Cfg<M, T, G>;
+  constexpr int N = C::N;
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n * N) return;
+  const long e = tid / N;
+  const int r = (int)(tid % N);
+  const long slot = idx ? (long)idx[e] : e;
+  if (x_in) *state_ptr<C, T>(rec, slot, r, N) = (T)x_in[e * N + r];
+  if (P_in)
+    for (int c = 0; c < N; ++c) *state_ptr<C, T>(rec, slot, r, c) = (T)P_in[(e * N + r) * N + c];
+  if constexpr (M::ANGULAR) {
+    if (uw_in && r < 3) *unwrap_ptr<C, T>(rec, slot, r) = (T)uw_in[e * 3 + r];
+  }
+}
+
+// copy the whole record of slot `src` over slot `dst` (erase = swap-with-last compaction)
+template <class M, typename T, int G>
+__global__ void move_record_kernel(char* rec, long src, long dst, double* t_base, int* nm_base) {
+  using C = Cfg<M, T, G>;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= C::G * C::RW) return;
+  const int i = tid / C::RW, w = tid % C::RW;
+  const T v = *reinterpret_cast<T*>(rec + (src / C::TPW) * C::TILE_BYTES +
+                                    record_word_offset<C, T>((int)(src % C::TPW) * C::G + i, w));
+  *reinterpret_cast<T*>(rec + (dst / C::TPW) * C::TILE_BYTES +
+                        record_word_offset<C, T>((int)(dst % C::TPW) * C::G + i, w)) = v;
+  if (tid == 0) { t_base[dst] = t_base[src]; nm_base[dst] = nm_base[src]; }
+}
+
+// measurements: AoS doubles [n][7] (the reference's Vector7d rows) -> SoA T [7][ld]
+template <typename T>
+__global__ void pack_meas_kernel(const double* aos, long n, T* soa, long ld) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+#pragma unroll
+  for (int c = 0; c < 7; ++c) soa[c * ld + e] = (T)aos[e * 7 + c];
+}
+
+struct OutArgs {
+  char* rec;
+  const int* idx;   // null: dense slots 0..n-1
+  long n;
+  double* pose;     // [n][7] or null
+  double* twist;    // [n][6] or null
+  double* acc;      // [n][6] or null
+  int at_time;      // 0: current outputs; 1: extrapolated to t1 (getEstimated*(t1))
+  double t1;        // absolute query time (at_time); NaN = each target's own time
+  double t_acc;     // batch clock; target time = t_base[slot] + t_acc
+  const double* t_base;
+};
+
+// Derived outputs of one target, from x only.
+//  current : updateTargetState + getEstimatedPose()/Twist()/Acceleration()
+//            (uniform_velocity.cpp:98-115, uniform_acceleration.cpp:101-118, angular_rates.cpp:117-138,
+//             angular_velocities.cpp:153-169, target_interface.cpp:100-115, geometry.hpp:590-608)
+//  at t1   : getEstimatedPose(t1)/Twist(t1)/Acceleration(t1)
+//            (uniform_velocity.cpp:117-133, uniform_acceleration.cpp:120-136, angular_rates.cpp:140-157,
+//             angular_velocities.cpp:171-184, target_interface.cpp:123-140)
+template <class M, typename T>
+__device__ __forceinline__ void derive_outputs(const T* x, bool at_time, T d, T* pose7, T* twist6, T* acc6) {
+  T R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  T pint[6] = {x[0], x[1], x[2], 0, 0, 0};  // pose_internal_
+#pragma unroll
+  for (int c = 0; c < 6; ++c) { twist6[c] = 0; acc6[c] = 0; }
+  if constexpr (M::TYPE == UNIFORM_VELOCITY) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) twist6[c] = x[3 + c];
+  } else if constexpr (M::TYPE == UNIFORM_ACCELERATION) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { twist6[c] = x[3 + c]; acc6[c] = x[6 + c]; }
+  } else {
+    T q[4];
+    rpy_to_quat(x + 3, q);
+    quat_to_rot(q, R);
+    rot_to_rpy(R, pint + 3);
+    if constexpr (M::TYPE == ANGULAR_RATES) {
+      // twist.angular = EarBase(rotToRpy(R)) * rates, geometry.hpp:333-351
+      T s_r, c_r, s_p, c_p;
+      Mth<T>::sincos(pint[3], &s_r, &c_r);
+      Mth<T>::sincos(pint[4], &s_p, &c_p);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) twist6[c] = x[6 + c];
+      twist6[3] = (1 * x[9] + 0 * x[10]) + (-s_p) * x[11];
+      twist6[4] = (0 * x[9] + c_r * x[10]) + (c_p * s_r) * x[11];
+      twist6[5] = (0 * x[9] + (-s_r) * x[10]) + (c_p * c_r) * x[11];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc6[c] = x[12 + c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) twist6[c] = x[6 + c];
+    }
+  }
+  if (!at_time) {
+    pose7[0] = x[0]; pose7[1] = x[1]; pose7[2] = x[2];
+    rot_to_quat(R, pose7 + 3);
+    return;
+  }
+  // extrapolation to t1 = t + d
+  if constexpr (M::TYPE == UNIFORM_VELOCITY) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pose7[c] = x[c] + twist6[c] * d;
+    pose7[3] = 0; pose7[4] = 0; pose7[5] = 0; pose7[6] = 1;
+  } else if constexpr (M::TYPE == UNIFORM_ACCELERATION) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pose7[c] = x[c] + twist6[c] * d + (T)0.5 * acc6[c] * d * d;
+    pose7[3] = 0; pose7[4] = 0; pose7[5] = 0; pose7[6] = 1;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) twist6[c] = twist6[c] + acc6[c] * d;
+  } else if constexpr (M::TYPE == ANGULAR_RATES) {
+    T v6[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) v6[c] = pint[c] + twist6[c] * d + (T)0.5 * acc6[c] * d * d;
+    pose7[0] = v6[0]; pose7[1] = v6[1]; pose7[2] = v6[2];
+    rpy_to_quat(v6 + 3, pose7 + 3);
+    quat_normalize(pose7 + 3);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) twist6[c] = twist6[c] + acc6[c] * d;
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pose7[c] = x[c] + twist6[c] * d;
+    T q0[4];
+    rpy_to_quat(pint + 3, q0);
+    qtran_apply(d, twist6 + 3, q0, pose7 + 3);
+    quat_normalize(pose7 + 3);
+  }
+}
+
+template <class M, typename T, int G>
+__global__ void outputs_kernel(const OutArgs a) {
+  using C = Cfg<M, T, G>;
+  constexpr int N = C::N;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.n) return;
+  const long slot = a.idx ? (long)a.idx[e] : e;
+  T x[N];
+#pragma unroll
+  for (int r = 0; r < N; ++r) x[r] = *state_ptr<C, T>(a.rec, slot, r, N);
+  T d = 0;
+  if (a.at_time) d = (a.t1 != a.t1) ? (T)0 : (T)(a.t1 - (a.t_base[slot] + a.t_acc));
+  T pose7[7], twist6[6], acc6[6];
+  derive_outputs<M, T>(x, a.at_time != 0, d, pose7, twist6, acc6);
+  if (a.pose) for (int c = 0; c < 7; ++c) a.pose[e * 7 + c] = (double)pose7[c];
+  if (a.twist) for (int c = 0; c < 6; ++c) a.twist[e * 6 + c] = (double)twist6[c];
+  if (a.acc) for (int c = 0; c < 6; ++c) a.acc[e * 6 + c] = (double)acc6[c];
+}
+
+}  // namespace te

@@ -1,0 +1,26 @@
+// kf_model_ar.hip -- kernel instantiations of one motion model (see kf_step.hpp).
+#include "kf_ops_impl.hpp"
+
+namespace te {
+
+const Ops* get_ops_ar(int dtype, int g) {
+  if (dtype == F64) {
+    if (g == 0) g = 6;
+    switch (g) {
+      case 3: return OpsImpl<ModelAR, double, 3>::get();
+      case 6: return OpsImpl<ModelAR, double, 6>::get();
+      default: return nullptr;
+    }
+  } else if (dtype == F32) {
+    if (g == 0) g = 6;
+    switch (g) {
+      case 2: return OpsImpl<ModelAR, float, 2>::get();
+      case 3: return OpsImpl<ModelAR, float, 3>::get();
+      case 6: return OpsImpl<ModelAR, float, 6>::get();
+      default: return nullptr;
+    }
+  }
+  return nullptr;
+}
+
+}  // namespace te

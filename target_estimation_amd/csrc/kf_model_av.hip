@@ -1,0 +1,26 @@
+// kf_model_av.hip -- kernel instantiations of one motion model (see kf_step.hpp).
+#include "kf_ops_impl.hpp"
+
+namespace te {
+
+const Ops* get_ops_av(int dtype, int g) {
+  if (dtype == F64) {
+    if (g == 0) g = 6;
+    switch (g) {
+      case 3: return OpsImpl<ModelAV, double, 3>::get();
+      case 6: return OpsImpl<ModelAV, double, 6>::get();
+      default: return nullptr;
+    }
+  } else if (dtype == F32) {
+    if (g == 0) g = 6;
+    switch (g) {
+      case 1: return OpsImpl<ModelAV, float, 1>::get();
+      case 3: return OpsImpl<ModelAV, float, 3>::get();
+      case 6: return OpsImpl<ModelAV, float, 6>::get();
+      default: return nullptr;
+    }
+  }
+  return nullptr;
+}
+
+}  // namespace te

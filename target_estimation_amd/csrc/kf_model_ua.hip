@@ -1,0 +1,25 @@
+// kf_model_ua.hip -- kernel instantiations of one motion model (see kf_step.hpp).
+#include "kf_ops_impl.hpp"
+
+namespace te {
+
+const Ops* get_ops_ua(int dtype, int g) {
+  if (dtype == F64) {
+    if (g == 0) g = 3;
+    switch (g) {
+      case 1: return OpsImpl<ModelUA, double, 1>::get();
+      case 3: return OpsImpl<ModelUA, double, 3>::get();
+      default: return nullptr;
+    }
+  } else if (dtype == F32) {
+    if (g == 0) g = 1;
+    switch (g) {
+      case 1: return OpsImpl<ModelUA, float, 1>::get();
+      case 3: return OpsImpl<ModelUA, float, 3>::get();
+      default: return nullptr;
+    }
+  }
+  return nullptr;
+}
+
+}  // namespace te

@@ -1,0 +1,45 @@
+// kf_ops.hpp -- type-erased launch table: one Ops per (model, precision, lanes-per-target).
+// The four kf_model_*.hip translation units instantiate the kernels; the host side
+// (batch_store.cpp) only sees this table.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kf_aux.hpp"
+#include "te_layout.hpp"
+
+namespace te {
+
+struct StepParams {
+  char* rec;
+  const void* qr;
+  long n;
+  const int* idx;                 // non-null selects the indexed kernel
+  const void* meas;               // SoA [7][meas_ld] in the batch precision, or null (predict only)
+  long meas_ld;
+  const unsigned char* has_meas;
+  const double* dt_per;
+  double dt;
+  double* t_base;
+  int* nm_base;
+};
+
+struct Ops {
+  LayoutInfo L;
+  int wpb;  // wavefronts per workgroup of the step kernel
+  void (*step)(const StepParams&, hipStream_t);
+  void (*init)(const InitArgs&, hipStream_t);
+  void (*get_state)(char* rec, const int* idx, long n, double* x, double* P, hipStream_t);
+  void (*set_state)(char* rec, const int* idx, long n, const double* x, const double* P, const double* uw, hipStream_t);
+  void (*move_record)(char* rec, long src, long dst, double* t_base, int* nm_base, hipStream_t);
+  void (*outputs)(const OutArgs&, hipStream_t);
+  void (*pack_meas)(const double* aos, long n, void* soa, long ld, hipStream_t);
+};
+
+// g == 0 selects the default lanes-per-target of the (model, precision); nullptr if unsupported
+const Ops* get_ops(int type, int dtype, int g);
+const Ops* get_ops_uv(int dtype, int g);
+const Ops* get_ops_ua(int dtype, int g);
+const Ops* get_ops_ar(int dtype, int g);
+const Ops* get_ops_av(int dtype, int g);
+
+}  // namespace te

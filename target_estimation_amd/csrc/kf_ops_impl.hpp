@@ -1,0 +1,60 @@
+// kf_ops_impl.hpp -- builds the Ops table entry of one (model, precision, G); included only by
+// the kf_model_*.hip translation units.
+#pragma once
+#include "kf_ops.hpp"
+#include "kf_step.hpp"
+
+namespace te {
+
+template <class M, typename T, int G>
+struct OpsImpl {
+  using C = Cfg<M, T, G>;
+
+  static void step(const StepParams& p, hipStream_t s) {
+    if (p.n <= 0) return;
+    StepArgs<T> a;
+    a.rec = p.rec; a.qr = static_cast<const T*>(p.qr); a.n = p.n; a.idx = p.idx;
+    a.meas = static_cast<const T*>(p.meas); a.meas_ld = p.meas_ld; a.has_meas = p.has_meas;
+    a.dt_per = p.dt_per; a.dt = p.dt; a.t_base = p.t_base; a.nm_base = p.nm_base;
+    const long waves = (p.n + C::TPW - 1) / C::TPW;
+    const unsigned blocks = (unsigned)((waves + C::WPB - 1) / C::WPB);
+    if (p.idx)
+      hipLaunchKernelGGL((kf_step_kernel<M, T, G, true>), dim3(blocks), dim3(C::WPB * 64), 0, s, a);
+    else
+      hipLaunchKernelGGL((kf_step_kernel<M, T, G, false>), dim3(blocks), dim3(C::WPB * 64), 0, s, a);
+  }
+  static void init(const InitArgs& a, hipStream_t s) {
+    if (a.n <= 0) return;
+    hipLaunchKernelGGL((init_kernel<M, T, G>), dim3((unsigned)((a.n + 127) / 128)), dim3(128), 0, s, a);
+  }
+  static void get_state(char* rec, const int* idx, long n, double* x, double* P, hipStream_t s) {
+    if (n <= 0) return;
+    const long th = n * C::N;
+    hipLaunchKernelGGL((get_state_kernel<M, T, G>), dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, rec, idx, n, x, P);
+  }
+  static void set_state(char* rec, const int* idx, long n, const double* x, const double* P, const double* uw, hipStream_t s) {
+    if (n <= 0) return;
+    const long th = n * C::N;
+    hipLaunchKernelGGL((set_state_kernel<M, T, G>), dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, rec, idx, n, x, P, uw);
+  }
+  static void move_record(char* rec, long src, long dst, double* t_base, int* nm_base, hipStream_t s) {
+    const int th = C::G * C::RW;
+    hipLaunchKernelGGL((move_record_kernel<M, T, G>), dim3((th + 255) / 256), dim3(256), 0, s, rec, src, dst, t_base, nm_base);
+  }
+  static void outputs(const OutArgs& a, hipStream_t s) {
+    if (a.n <= 0) return;
+    hipLaunchKernelGGL((outputs_kernel<M, T, G>), dim3((unsigned)((a.n + 127) / 128)), dim3(128), 0, s, a);
+  }
+  static void pack_meas(const double* aos, long n, void* soa, long ld, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL((pack_meas_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, aos, n, static_cast<T*>(soa), ld);
+  }
+  static const Ops* get() {
+    static const Ops ops = {
+        LayoutInfo{C::N, C::K, G, C::TPW, C::LPT, C::RW, C::TILE_BYTES, C::TILE_PAYLOAD},
+        C::WPB, &step, &init, &get_state, &set_state, &move_record, &outputs, &pack_meas};
+    return &ops;
+  }
+};
+
+}  // namespace te

@@ -1,0 +1,461 @@
+// kf_step.hpp -- the fused predict+update kernel of the batched Kalman path (gfx950).
+//
+// What one launch does, per target (reference call it replaces in brackets):
+//   updateA(dt)                      [src/types/*.cpp updateA; AV: Jacobians at the previous posterior]
+//   measurement conversion           [addMeasurement: xyz, or quat -> normalise -> rpy -> unwrap]
+//   x^- = A x | f(x);  P^- = (A P) A^T + Q          [src/kalman.cpp:84-88 | :129-133]
+//   S = P^-[0:m,0:m] + R;  K = P^-[:,0:m] S^-1      [src/kalman.cpp:92 | :137]
+//   x^+ = x^- + K (y - x^-[0:m])                    [src/kalman.cpp:93 | :138]
+//   P^+ = (I - K C) P^-   (NOT Joseph form)         [src/kalman.cpp:94 | :139]
+// C = [I_m 0] in every model, so C P C^T / P C^T / K C are selections (zero flops).
+//
+// Execution model: G lanes cooperate on one target (te_layout.hpp); each lane keeps its rows of
+// P in VGPRs for the whole step.  The banded / block transition is applied in registers; the
+// only cross-lane traffic is, per step and target, through a per-wavefront LDS scratch:
+// the pivot rows of the Gauss-Jordan inverse of S, S^-1 (K x K), the innovation (K) and the
+// top K rows of P^- (K x N).  A wavefront owns its scratch, so no s_barrier is executed after
+// the one that publishes Q and R.  With G = 1 (thread per target) there is no exchange at all.
+//
+// Summation order follows the reference's dense products (k ascending; the structural zeros
+// of A and C contribute exact zeros), with fma in place of mul+add.  S is inverted by
+// unpivoted Gauss-Jordan (S is SPD); the reference's Eigen inverse is partial-pivot LU: same
+// result to rounding, covered by the stated tolerance.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "te_device_math.hpp"
+#include "te_layout.hpp"
+
+namespace te {
+
+template <typename T>
+struct StepArgs {
+  char* rec;                 // lane records, tile-major (te_layout.hpp)
+  const T* qr;               // Q (N*N row-major) then R (K*K row-major), compute precision
+  long n;                    // dense: number of targets; indexed: number of entries
+  const int* idx;            // indexed only: slot of entry e
+  const T* meas;             // SoA [7][meas_ld]; row c = component c of [x y z qx qy qz qw]; may be null (predict only)
+  long meas_ld;
+  const unsigned char* has_meas;  // per entry; null = every entry has a measurement (if meas != null)
+  const double* dt_per;      // indexed only, optional per-entry dt
+  double dt;
+  double* t_base;            // per-slot time offset       (touched by the indexed path only)
+  int* nm_base;              // per-slot measurement count (touched when a mask is given or indexed)
+};
+
+template <typename T> struct Vec16;
+template <> struct Vec16<double> { using type = double2; };
+template <> struct Vec16<float> { using type = float4; };
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // same-wavefront LDS hand-off: DS instructions of one wave execute in order, so this only has
+  // to stop the compiler from moving LDS accesses across it
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <class C, typename T>
+__device__ __forceinline__ void load_record(const char* tb, int lane, T* rec) {
+  using V = typename Vec16<T>::type;
+#pragma unroll
+  for (int c = 0; c < C::NC; ++c) {
+    V v = *reinterpret_cast<const V*>(tb + (long)c * C::LPT * 16 + (long)lane * 16);
+    if constexpr (sizeof(T) == 8) { rec[c * 2] = v.x; rec[c * 2 + 1] = v.y; }
+    else { rec[c * 4] = v.x; rec[c * 4 + 1] = v.y; rec[c * 4 + 2] = v.z; rec[c * 4 + 3] = v.w; }
+  }
+  if constexpr (C::REM2) {
+    float2 v = *reinterpret_cast<const float2*>(tb + C::TAIL2_OFF + (long)lane * 8);
+    rec[C::NC * C::VW] = v.x; rec[C::NC * C::VW + 1] = v.y;
+  }
+  if constexpr (C::REM1) rec[C::RW - 1] = *reinterpret_cast<const T*>(tb + C::TAIL1_OFF + (long)lane * (long)sizeof(T));
+}
+
+template <class C, typename T>
+__device__ __forceinline__ void store_record(char* tb, int lane, const T* rec) {
+  using V = typename Vec16<T>::type;
+#pragma unroll
+  for (int c = 0; c < C::NC; ++c) {
+    V v;
+    if constexpr (sizeof(T) == 8) { v.x = rec[c * 2]; v.y = rec[c * 2 + 1]; }
+    else { v.x = rec[c * 4]; v.y = rec[c * 4 + 1]; v.z = rec[c * 4 + 2]; v.w = rec[c * 4 + 3]; }
+    *reinterpret_cast<V*>(tb + (long)c * C::LPT * 16 + (long)lane * 16) = v;
+  }
+  if constexpr (C::REM2) {
+    float2 v; v.x = rec[C::NC * C::VW]; v.y = rec[C::NC * C::VW + 1];
+    *reinterpret_cast<float2*>(tb + C::TAIL2_OFF + (long)lane * 8) = v;
+  }
+  if constexpr (C::REM1) *reinterpret_cast<T*>(tb + C::TAIL1_OFF + (long)lane * (long)sizeof(T)) = rec[C::RW - 1];
+}
+
+template <typename T> __device__ __forceinline__ T sel3(int c, T a, T b, T d) { return c == 0 ? a : (c == 1 ? b : d); }
+
+template <class M, typename T, int G, bool INDEXED>
+__global__ void __launch_bounds__((Cfg<M, T, G>::WPB * 64)) kf_step_kernel(const StepArgs<T> a) {
+  using C = Cfg<M, T, G>;
+  constexpr int N = C::N, K = C::K, RPL = C::RPL, KPL = C::KPL, TPW = C::TPW, GS = C::GS;
+  constexpr int kStepWaves = C::WPB, kStepThreads = C::WPB * 64;
+  using F = Mth<T>;
+
+  __shared__ T s_qr[N * N + K * K];
+  __shared__ T s_ex[(C::EX_WORDS > 0 ? C::EX_WORDS : 1) * kStepWaves];
+
+  for (int e = threadIdx.x; e < N * N + K * K; e += kStepThreads) s_qr[e] = a.qr[e];
+  __syncthreads();
+  const T* sQ = s_qr;
+  const T* sR = s_qr + N * N;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const long wg = (long)blockIdx.x * kStepWaves + wave;  // wavefront-global index
+  if (wg * TPW >= a.n) return;                           // wave-uniform; no block barrier follows
+  const int g = lane / G;
+  const int i = (G == 1) ? 0 : lane % G;
+  const long entry = wg * TPW + g;
+  const bool valid = (lane < C::LPT) && (entry < a.n);
+
+  long tile;
+  int lt;  // lane inside the tile
+  if constexpr (INDEXED) {
+    const long slot = valid ? (long)a.idx[entry] : 0;
+    tile = slot / TPW;
+    lt = (int)(slot % TPW) * G + i;
+  } else {
+    tile = wg;
+    lt = lane;
+  }
+  char* tb = a.rec + tile * C::TILE_BYTES;
+
+  T rec[C::RW];
+  if (valid) {
+    load_record<C, T>(tb, lt, rec);
+  } else {
+#pragma unroll
+    for (int w = 0; w < C::RW; ++w) rec[w] = 0;
+  }
+  // views into the record (compile-time indices only)
+#define P_(q, c) rec[(q) * N + (c)]
+#define X_(q) rec[C::X_OFF + (q)]
+#define UW_(s) rec[C::UW_OFF + (s)]
+
+  // per-wave LDS scratch: element `idx` of this lane's target at [idx*GS + g]
+  T* sx = s_ex + (C::EX_WORDS > 0 ? C::EX_WORDS : 1) * wave;
+#define EXA_(idx) sx[(idx) * GS + g]
+#define EXB_(idx) sx[(C::EXA + (idx)) * GS + g]
+#define EXC_(idx) sx[(C::EXA + C::EXB + (idx)) * GS + g]
+
+  double dtd = a.dt;
+  if constexpr (INDEXED) {
+    if (a.dt_per && valid) dtd = a.dt_per[entry];
+  }
+  const T dt = (T)dtd;
+  const bool has = valid && a.meas != nullptr && (a.has_meas == nullptr || a.has_meas[entry] != 0);
+
+  // ------------------------------------------------------------------ measurement conversion
+  // angular models: quaternion -> normalise -> rpy (every lane of the group redundantly)
+  T mrpy[3] = {0, 0, 0};
+  if constexpr (M::ANGULAR) {
+    if (has) {
+      T q[4];
+      q[0] = a.meas[3 * a.meas_ld + entry];
+      q[1] = a.meas[4 * a.meas_ld + entry];
+      q[2] = a.meas[5 * a.meas_ld + entry];
+      q[3] = a.meas[6 * a.meas_ld + entry];
+      quat_normalize(q);
+      quat_to_rpy(q, mrpy);
+    }
+  }
+
+  // ------------------------------------------------------------------ predict
+  if constexpr (!M::EKF) {
+    const T hdt = (T)0.5 * dt * dt;  // angular_rates.cpp:114 / uniform_acceleration.cpp:98
+    // x^- = A x  and  AP = A*P: rows r, r+K, r+2K are q, q+KPL, q+2KPL of this lane
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) {
+      const int b = q / KPL;  // block of this row
+      if (b + 1 < C::NB) {
+        X_(q) = F::fma(dt, X_(q + KPL), X_(q));
+        if (C::NB == 3 && b == 0) X_(q) = F::fma(hdt, X_(q + 2 * KPL), X_(q));
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+          T v = F::fma(dt, P_(q + KPL, c), P_(q, c));
+          if (C::NB == 3 && b == 0) v = F::fma(hdt, P_(q + 2 * KPL, c), v);
+          P_(q, c) = v;
+        }
+      }
+    }
+    // (AP) * A^T, column blocks, then + Q
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) {
+      const int r = i + G * (q % KPL) + K * (q / KPL);
+#pragma unroll
+      for (int c = 0; c < N; ++c) {
+        const int bc = c / K;
+        T v = P_(q, c);
+        if (bc + 1 < C::NB) {
+          v = F::fma(dt, P_(q, c + K), v);
+          if (C::NB == 3 && bc == 0) v = F::fma(hdt, P_(q, c + 2 * K), v);
+        }
+        P_(q, c) = v + sQ[r * N + c];
+      }
+    }
+  } else {
+    // ---- EKF (angular velocities): A blocks of angular_velocities.cpp:116-124 evaluated at
+    // the previous posterior, f of :126-140.  Rows: [xyz rpy | vel omega], K = 6, NB = 2.
+    T rpy[3], om[3];
+    if constexpr (G == 1) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { rpy[c] = X_(3 + c); om[c] = X_(9 + c); }
+    } else {
+#pragma unroll
+      for (int q = 0; q < RPL; ++q) EXC_(i + G * (q % KPL) + K * (q / KPL)) = X_(q);
+      wave_lds_fence();
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { rpy[c] = EXC_(3 + c); om[c] = EXC_(9 + c); }
+    }
+    T s_r, c_r, s_p, c_p;
+    F::sincos(rpy[0], &s_r, &c_r);
+    F::sincos(rpy[1], &s_p, &c_p);
+    const T wy = om[1], wz = om[2];
+    // geometry.hpp:394-410 EarBaseInvJacobianRpy and :412-426 EarBaseInvJacobianOmega
+    T Jr[3][3], Jw[3][3], Ei[3][3];
+    Jr[0][0] = (dt * (wy * c_r * s_p - wz * s_p * s_r)) / c_p + 1;
+    Jr[0][1] = (dt * (wz * c_r + wy * s_r)) / (c_p * c_p);
+    Jr[0][2] = 0;
+    Jr[1][0] = -dt * (wz * c_r + wy * s_r);
+    Jr[1][1] = 1;
+    Jr[1][2] = 0;
+    Jr[2][0] = (dt * (wy * c_r - wz * s_r)) / c_p;
+    Jr[2][1] = (dt * s_p * (wz * c_r + wy * s_r)) / (c_p * c_p);
+    Jr[2][2] = 1;
+    Jw[0][0] = dt; Jw[0][1] = (dt * s_p * s_r) / c_p; Jw[0][2] = (dt * c_r * s_p) / c_p;
+    Jw[1][0] = 0;  Jw[1][1] = dt * c_r;               Jw[1][2] = -dt * s_r;
+    Jw[2][0] = 0;  Jw[2][1] = (dt * s_r) / c_p;       Jw[2][2] = (dt * c_r) / c_p;
+    // geometry.hpp:359-374 rpyToEarBaseInv
+    Ei[0][0] = 1; Ei[0][1] = (s_p * s_r) / c_p; Ei[0][2] = (c_r * s_p) / c_p;
+    Ei[1][0] = 0; Ei[1][1] = c_r;               Ei[1][2] = -s_r;
+    Ei[2][0] = 0; Ei[2][1] = s_r / c_p;         Ei[2][2] = c_r / c_p;
+
+    // rows 3..5 and 9..11 of P are needed by the rpy rows of A*P
+    T mid[6][N];
+    if constexpr (G == 1) {
+#pragma unroll
+      for (int c = 0; c < N; ++c) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { mid[k][c] = P_(3 + k, c); mid[3 + k][c] = P_(9 + k, c); }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < RPL; ++q) {
+        const int r = i + G * (q % KPL) + K * (q / KPL);
+        const int rr = r % 6;  // 3..5 for the rows of interest
+        if (rr >= 3) {
+          const int m6 = (r >= 6 ? 3 : 0) + (rr - 3);
+#pragma unroll
+          for (int c = 0; c < N; ++c) EXA_(m6 * N + c) = P_(q, c);
+        }
+      }
+      wave_lds_fence();
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int c = 0; c < N; ++c) mid[k][c] = EXA_(k * N + c);
+    }
+    // x^- = f(x) and the top half of A*P (rows 6..11 are unchanged)
+#pragma unroll
+    for (int q = 0; q < KPL; ++q) {
+      const int r = i + G * q;  // < 6
+      const int cc = r - 3;
+      const bool rot = r >= 3;
+      const T e0 = sel3(cc, Ei[0][0], Ei[1][0], Ei[2][0]);
+      const T e1 = sel3(cc, Ei[0][1], Ei[1][1], Ei[2][1]);
+      const T e2 = sel3(cc, Ei[0][2], Ei[1][2], Ei[2][2]);
+      T acc = (dt * e0) * om[0];
+      acc = F::fma(dt * e1, om[1], acc);
+      acc = F::fma(dt * e2, om[2], acc);
+      const T xlin = F::fma(dt, X_(q + KPL), X_(q));
+      X_(q) = rot ? X_(q) + acc : xlin;
+      const T jr0 = sel3(cc, Jr[0][0], Jr[1][0], Jr[2][0]), jr1 = sel3(cc, Jr[0][1], Jr[1][1], Jr[2][1]),
+              jr2 = sel3(cc, Jr[0][2], Jr[1][2], Jr[2][2]);
+      const T jw0 = sel3(cc, Jw[0][0], Jw[1][0], Jw[2][0]), jw1 = sel3(cc, Jw[0][1], Jw[1][1], Jw[2][1]),
+              jw2 = sel3(cc, Jw[0][2], Jw[1][2], Jw[2][2]);
+#pragma unroll
+      for (int c = 0; c < N; ++c) {
+        T v = jr0 * mid[0][c];
+        v = F::fma(jr1, mid[1][c], v);
+        v = F::fma(jr2, mid[2][c], v);
+        v = F::fma(jw0, mid[3][c], v);
+        v = F::fma(jw1, mid[4][c], v);
+        v = F::fma(jw2, mid[5][c], v);
+        const T lin = F::fma(dt, P_(q + KPL, c), P_(q, c));
+        P_(q, c) = rot ? v : lin;
+      }
+    }
+    // (AP) * A^T in registers, + Q
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) {
+      const int r = i + G * (q % KPL) + K * (q / KPL);
+      T nw[6];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) nw[j] = F::fma(dt, P_(q, j + 6), P_(q, j));
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        T v = P_(q, 3) * Jr[cc][0];
+        v = F::fma(P_(q, 4), Jr[cc][1], v);
+        v = F::fma(P_(q, 5), Jr[cc][2], v);
+        v = F::fma(P_(q, 9), Jw[cc][0], v);
+        v = F::fma(P_(q, 10), Jw[cc][1], v);
+        v = F::fma(P_(q, 11), Jw[cc][2], v);
+        nw[3 + cc] = v;
+      }
+#pragma unroll
+      for (int c = 0; c < N; ++c) P_(q, c) = (c < 6 ? nw[c < 6 ? c : 0] : P_(q, c)) + sQ[r * N + c];
+    }
+  }
+
+  // ------------------------------------------------------------------ update (estimate)
+  if (has) {
+    // S = P^-[0:K,0:K] + R, rows owned by this lane; unpivoted in-place Gauss-Jordan
+    T S[KPL][K];
+#pragma unroll
+    for (int qq = 0; qq < KPL; ++qq)
+#pragma unroll
+      for (int c = 0; c < K; ++c) S[qq][c] = P_(qq, c) + sR[(i + G * qq) * K + c];
+#pragma unroll
+    for (int p = 0; p < K; ++p) {
+      const int ip = p % G, qp = p / G;
+      T prow[K];
+      if constexpr (G == 1) {
+        const T inv = (T)1 / S[qp][p];
+        S[qp][p] = 1;
+#pragma unroll
+        for (int c = 0; c < K; ++c) { S[qp][c] *= inv; prow[c] = S[qp][c]; }
+      } else {
+        if (i == ip) {
+          const T inv = (T)1 / S[qp][p];
+          S[qp][p] = 1;
+#pragma unroll
+          for (int c = 0; c < K; ++c) { S[qp][c] *= inv; EXC_(c) = S[qp][c]; }
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int c = 0; c < K; ++c) prow[c] = EXC_(c);
+        wave_lds_fence();
+      }
+#pragma unroll
+      for (int qq = 0; qq < KPL; ++qq) {
+        const bool is_piv = (qq == qp) && (i == ip);
+        const T f = is_piv ? (T)0 : S[qq][p];
+        if (!is_piv) S[qq][p] = 0;
+#pragma unroll
+        for (int c = 0; c < K; ++c) S[qq][c] = F::fma(-f, prow[c], S[qq][c]);
+      }
+    }
+    // publish S^-1 and the top K rows of P^- (both needed by every lane of the group)
+    if constexpr (G > 1) {
+#pragma unroll
+      for (int qq = 0; qq < KPL; ++qq) {
+#pragma unroll
+        for (int c = 0; c < K; ++c) EXB_((i + G * qq) * K + c) = S[qq][c];
+#pragma unroll
+        for (int c = 0; c < N; ++c) EXA_((i + G * qq) * N + c) = P_(qq, c);
+      }
+    }
+    // innovation y - x^-[0:K]; y = xyz | unwrapped rpy (angular_rates.cpp:81-88)
+    T nu[K];
+    {
+      T nu_own[KPL];
+#pragma unroll
+      for (int qq = 0; qq < KPL; ++qq) {
+        const int r = i + G * qq;
+        T y;
+        if (!M::ANGULAR || r < 3) {
+          y = a.meas[(long)r * a.meas_ld + entry];
+        } else {
+          const int cc = r - 3;
+          const int us = cc / G;
+          T prev = 0;
+#pragma unroll
+          for (int s = 0; s < C::UW; ++s) prev = (s == us) ? UW_(s) : prev;
+          y = unwrap_angle(prev, sel3(cc, mrpy[0], mrpy[1], mrpy[2]));
+#pragma unroll
+          for (int s = 0; s < C::UW; ++s) UW_(s) = (s == us) ? y : UW_(s);
+        }
+        nu_own[qq] = y - X_(qq);
+        if constexpr (G > 1) EXC_(r) = nu_own[qq];
+      }
+      if constexpr (G == 1) {
+#pragma unroll
+        for (int l = 0; l < K; ++l) nu[l] = nu_own[l];
+      }
+    }
+    if constexpr (G > 1) {
+      wave_lds_fence();
+#pragma unroll
+      for (int l = 0; l < K; ++l) nu[l] = EXC_(l);
+    }
+    // K = (P^- C^T) S^-1, rows of this lane
+    T Kg[RPL][K];
+#pragma unroll
+    for (int l = 0; l < K; ++l)
+#pragma unroll
+      for (int c = 0; c < K; ++c) {
+        T v;
+        if constexpr (G == 1) v = S[c][l]; else v = EXB_(c * K + l);
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) Kg[q][l] = (c == 0) ? P_(q, 0) * v : F::fma(P_(q, c), v, Kg[q][l]);
+      }
+    // x^+ = x^- + K nu
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) {
+      T acc = Kg[q][0] * nu[0];
+#pragma unroll
+      for (int l = 1; l < K; ++l) acc = F::fma(Kg[q][l], nu[l], acc);
+      X_(q) += acc;
+    }
+    // P^+ = (I - K C) P^-: D = I - K C has columns 0..K-1 and the diagonal
+    T D[RPL][K];
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) {
+      const int r = i + G * (q % KPL) + K * (q / KPL);
+#pragma unroll
+      for (int j = 0; j < K; ++j) D[q][j] = ((r == j) ? (T)1 : (T)0) - Kg[q][j];
+    }
+    T top[K];  // column c of the top K rows of P^-
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        if constexpr (G == 1) top[j] = P_(j, c); else top[j] = EXA_(j * N + c);
+      }
+#pragma unroll
+      for (int q = 0; q < RPL; ++q) {
+        T acc = D[q][0] * top[0];
+#pragma unroll
+        for (int j = 1; j < K; ++j) acc = F::fma(D[q][j], top[j], acc);
+        P_(q, c) = (q < KPL) ? acc : acc + P_(q, c);
+      }
+    }
+  }
+
+  if (valid) {
+    store_record<C, T>(tb, lt, rec);
+    if (i == 0) {
+      if constexpr (INDEXED) {
+        const long slot = a.idx[entry];
+        a.t_base[slot] += dtd;
+        if (has) a.nm_base[slot] += 1;
+      } else {
+        if (a.has_meas != nullptr && has) a.nm_base[entry] += 1;
+      }
+    }
+  }
+#undef P_
+#undef X_
+#undef UW_
+#undef EXA_
+#undef EXB_
+#undef EXC_
+}
+
+}  // namespace te

@@ -1,0 +1,426 @@
+// target_manager.cpp -- see target_manager.hpp.
+#include "target_manager.hpp"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+
+#include "hip_check.hpp"
+#include "yaml_mini.hpp"
+
+namespace te {
+
+using std::lock_guard;
+using std::mutex;
+
+static const double kZero6[6] = {0, 0, 0, 0, 0, 0};
+
+TargetManager::TargetManager(int dtype, int lanes_per_target) : dtype_(dtype), lanes_(lanes_per_target) {
+  const char* v = std::getenv("TARGET_ESTIMATION_VERBOSE");
+  verbose_ = v && v[0] && v[0] != '0';
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+    throw std::runtime_error("target_estimation_amd: no HIP device available; this library has no CPU path");
+}
+
+TargetManager::TargetManager(const std::string& file, int dtype, int lanes_per_target)
+    : TargetManager(dtype, lanes_per_target) {
+  if (!loadYamlFile(file, default_Q_, default_R_, default_P_, default_type_))
+    throw "TargetManager default constructor failed!";
+  else
+    default_values_loaded_ = true;
+}
+
+TargetManager::~TargetManager() {}
+
+bool TargetManager::selectTargetType(const std::string& type_str, target_t& type) {
+  if (type_str == "angular_rates") type = ANGULAR_RATES;
+  else if (type_str == "angular_velocities") type = ANGULAR_VELOCITIES;
+  else if (type_str == "uniform_acceleration") type = UNIFORM_ACCELERATION;
+  else if (type_str == "uniform_velocity") type = UNIFORM_VELOCITY;
+  else return false;
+  return true;
+}
+
+bool TargetManager::loadYamlFile(const std::string& file, std::vector<double>& Q, std::vector<double>& R,
+                                 std::vector<double>& P, target_t& type) {
+  bool success = true;
+  ModelFile mf;
+  std::string err;
+  if (!load_model_file(file, mf, err)) {
+    std::cerr << err << std::endl;
+    return false;
+  }
+  if (!selectTargetType(mf.type, type)) {
+    std::cerr << "Can not parse type: " << mf.type << std::endl;
+    std::cerr << "Can not load type from file: " << file << std::endl;
+    return false;
+  }
+  const size_t n = (size_t)model_n((int)type), m = (size_t)model_m((int)type);
+  const char* names[3] = {"Q", "R", "P"};
+  std::vector<double>* dst[3] = {&Q, &R, &P};
+  const size_t want[3] = {n * n, m * m, n * n};
+  for (int k = 0; k < 3; ++k) {
+    auto it = mf.seqs.find(names[k]);
+    if (it == mf.seqs.end() || it->second.size() != want[k]) {
+      // the reference maps any square list; its models then assert n (uniform_velocity.cpp:34 ...)
+      std::cerr << "Can not load matrix " << names[k] << " from file: " << file << std::endl;
+      success = false;
+      continue;
+    }
+    // The reference maps the row-major YAML list column-major (target_manager.cpp:25), i.e. it
+    // reads the transpose.  Reproduce that exactly (immaterial for the symmetric shipped models).
+    const size_t s = (size_t)std::llround(std::sqrt((double)want[k]));
+    dst[k]->assign(want[k], 0.0);
+    for (size_t r = 0; r < s; ++r)
+      for (size_t c = 0; c < s; ++c) (*dst[k])[r * s + c] = it->second[c * s + r];
+  }
+  return success;
+}
+
+int TargetManager::findOrCreateBatch(int type, const double* Q, const double* R) {
+  for (size_t b = 0; b < batches_.size(); ++b)
+    if (batches_[b]->same_params(type, Q, R)) return (int)b;
+  batches_.emplace_back(new Batch(type, dtype_, lanes_, Q, R, stream_));
+  return (int)batches_.size() - 1;
+}
+
+bool TargetManager::find(unsigned id, Loc& loc) {
+  auto it = targets_.find(id);
+  if (it == targets_.end()) return false;
+  loc = it->second;
+  return true;
+}
+
+void TargetManager::log() {}
+
+std::vector<unsigned> TargetManager::getAvailableTargets() {
+  std::vector<unsigned> ids;
+  lock_guard<mutex> lg(target_lock_);
+  ids.reserve(targets_.size());
+  for (auto const& kv : targets_) ids.push_back(kv.first);
+  return ids;
+}
+
+size_t TargetManager::size() {
+  lock_guard<mutex> lg(target_lock_);
+  return targets_.size();
+}
+
+bool TargetManager::hasTarget(unsigned id) {
+  lock_guard<mutex> lg(target_lock_);
+  return targets_.count(id) != 0;
+}
+
+void TargetManager::init(unsigned id, double dt0, double t0, const double* p0, const double* v0, const double* a0) {
+  if (default_values_loaded_)
+    init(default_type_, id, dt0, t0, default_Q_.data(), default_R_.data(), default_P_.data(), p0, v0, a0);
+  else
+    throw "TargetManager::init failed, can not find default values to load!";
+}
+
+void TargetManager::init(target_t type, unsigned id, double dt0, double t0, const double* Q, const double* R,
+                         const double* P0, const double* p0, const double* v0, const double* a0) {
+  (void)dt0;  // only shapes the constructor's A, which every step rebuilds (uniform_velocity.cpp:40,67)
+  lock_guard<mutex> lg(target_lock_);
+  if (targets_.find(id) == targets_.end()) {
+    const int b = findOrCreateBatch((int)type, Q, R);
+    const long slot = batches_[(size_t)b]->append(1, &id, t0, P0, false, p0, v0 ? v0 : kZero6, a0 ? a0 : kZero6);
+    targets_[id] = Loc{b, (int)slot};
+    if (verbose_) {
+      switch (type) {
+        case ANGULAR_RATES: std::cout << "Using angular rates for the orientation" << std::endl; break;
+        case ANGULAR_VELOCITIES: std::cout << "Using angular velocities for the orientation" << std::endl; break;
+        case UNIFORM_ACCELERATION: std::cout << "Uniformly accelerated motion" << std::endl; break;
+        case UNIFORM_VELOCITY: std::cout << "Uniform rectilinear motion" << std::endl; break;
+      }
+    }
+  } else
+    std::cout << "Target(" << id << ") already exists!" << std::endl;
+}
+
+void TargetManager::init(const std::string& file, unsigned id, double dt0, double t0, const double* p0,
+                         const double* v0, const double* a0) {
+  std::vector<double> Q, R, P;
+  target_t type = UNIFORM_VELOCITY;
+  if (!loadYamlFile(file, Q, R, P, type)) throw "TargetManager::init failed, can not load the model file!";
+  init(type, id, dt0, t0, Q.data(), R.data(), P.data(), p0, v0, a0);
+}
+
+long TargetManager::initBatch(const unsigned* ids, long n, double dt0, double t0, const double* p0, const double* v0,
+                              const double* a0) {
+  if (!default_values_loaded_) throw "TargetManager::init failed, can not find default values to load!";
+  return initBatch(default_type_, ids, n, dt0, t0, default_Q_.data(), default_R_.data(), default_P_.data(), false, p0, v0, a0);
+}
+
+long TargetManager::initBatch(target_t type, const unsigned* ids, long n, double dt0, double t0, const double* Q,
+                              const double* R, const double* P0, bool per_target_P0, const double* p0,
+                              const double* v0, const double* a0) {
+  (void)dt0;
+  lock_guard<mutex> lg(target_lock_);
+  const int N = model_n((int)type);
+  // keep only ids that do not exist yet (existing ones are left untouched, as in init())
+  std::vector<long> keep;
+  keep.reserve((size_t)n);
+  {
+    std::map<unsigned, int> seen;
+    for (long i = 0; i < n; ++i) {
+      if (targets_.count(ids[i]) || seen.count(ids[i])) {
+        if (verbose_) std::cout << "Target(" << ids[i] << ") already exists!" << std::endl;
+        continue;
+      }
+      seen[ids[i]] = 1;
+      keep.push_back(i);
+    }
+  }
+  if (keep.empty()) return 0;
+  const long k = (long)keep.size();
+  const int b = findOrCreateBatch((int)type, Q, R);
+  long first;
+  if (k == n) {
+    first = batches_[(size_t)b]->append(n, ids, t0, P0, per_target_P0, p0, v0, a0);
+  } else {
+    std::vector<unsigned> ids2((size_t)k);
+    std::vector<double> p2((size_t)k * 7), v2, a2, P2;
+    if (v0) v2.resize((size_t)k * 6);
+    if (a0) a2.resize((size_t)k * 6);
+    if (per_target_P0) P2.resize((size_t)k * N * N);
+    for (long j = 0; j < k; ++j) {
+      const long i = keep[(size_t)j];
+      ids2[(size_t)j] = ids[i];
+      std::memcpy(&p2[(size_t)j * 7], p0 + i * 7, sizeof(double) * 7);
+      if (v0) std::memcpy(&v2[(size_t)j * 6], v0 + i * 6, sizeof(double) * 6);
+      if (a0) std::memcpy(&a2[(size_t)j * 6], a0 + i * 6, sizeof(double) * 6);
+      if (per_target_P0) std::memcpy(&P2[(size_t)j * N * N], P0 + i * N * N, sizeof(double) * N * N);
+    }
+    first = batches_[(size_t)b]->append(k, ids2.data(), t0, per_target_P0 ? P2.data() : P0, per_target_P0, p2.data(),
+                                        v0 ? v2.data() : nullptr, a0 ? a2.data() : nullptr);
+  }
+  for (long j = 0; j < k; ++j) targets_[ids[keep[(size_t)j]]] = Loc{b, (int)(first + j)};
+  return k;
+}
+
+bool TargetManager::update(unsigned id, double dt, const double* meas) {
+  lock_guard<mutex> lg(target_lock_);
+  Loc loc;
+  if (!find(id, loc)) {
+    std::cout << "Target(" << id << ") does not exist!" << std::endl;
+    return false;
+  }
+  batches_[(size_t)loc.batch]->step_one(loc.slot, dt, meas);
+  return true;
+}
+
+bool TargetManager::update(unsigned id, double dt) {
+  lock_guard<mutex> lg(target_lock_);
+  Loc loc;
+  if (!find(id, loc)) {
+    std::cout << "Target(" << id << ") does not exist!" << std::endl;
+    return false;
+  }
+  batches_[(size_t)loc.batch]->step_one(loc.slot, dt, nullptr);
+  return true;
+}
+
+void TargetManager::update(double dt) {
+  lock_guard<mutex> lg(target_lock_);
+  for (auto& b : batches_) b->step_dense(dt, nullptr, 0, nullptr);
+}
+
+bool TargetManager::erase(unsigned id) {
+  lock_guard<mutex> lg(target_lock_);
+  Loc loc;
+  if (!find(id, loc)) {
+    std::cout << "Target(" << id << ") does not exist!" << std::endl;
+    return false;
+  }
+  Batch* b = batches_[(size_t)loc.batch].get();
+  const bool was_last = loc.slot == b->size() - 1;
+  const unsigned moved = b->erase_slot(loc.slot);
+  targets_.erase(id);
+  if (!was_last) targets_[moved].slot = loc.slot;
+  return true;
+}
+
+bool TargetManager::getTargetPose(unsigned id, double* pose7) {
+  lock_guard<mutex> lg(target_lock_);
+  Loc loc;
+  if (!find(id, loc)) return false;
+  batches_[(size_t)loc.batch]->outputs_one(loc.slot, pose7, nullptr, nullptr, false, 0.0);
+  return true;
+}
+
+bool TargetManager::getTargetTwist(unsigned id, double* twist6) {
+  lock_guard<mutex> lg(target_lock_);
+  Loc loc;
+  if (!find(id, loc)) return false;
+  batches_[(size_t)loc.batch]->outputs_one(loc.slot, nullptr, twist6, nullptr, false, 0.0);
+  return true;
+}
+
+bool TargetManager::getTargetAcceleration(unsigned id, double* acc6) {
+  lock_guard<mutex> lg(target_lock_);
+  Loc loc;
+  if (!find(id, loc)) return false;
+  batches_[(size_t)loc.batch]->outputs_one(loc.slot, nullptr, nullptr, acc6, false, 0.0);
+  return true;
+}
+
+bool TargetManager::getTargetPoseAt(unsigned id, double t1, double* pose7) {
+  lock_guard<mutex> lg(target_lock_);
+  Loc loc;
+  if (!find(id, loc)) return false;
+  batches_[(size_t)loc.batch]->outputs_one(loc.slot, pose7, nullptr, nullptr, true, t1);
+  return true;
+}
+
+bool TargetManager::getTargetTwistAt(unsigned id, double t1, double* twist6) {
+  lock_guard<mutex> lg(target_lock_);
+  Loc loc;
+  if (!find(id, loc)) return false;
+  batches_[(size_t)loc.batch]->outputs_one(loc.slot, nullptr, twist6, nullptr, true, t1);
+  return true;
+}
+
+bool TargetManager::getTargetAccelerationAt(unsigned id, double t1, double* a6) {
+  lock_guard<mutex> lg(target_lock_);
+  Loc loc;
+  if (!find(id, loc)) return false;
+  batches_[(size_t)loc.batch]->outputs_one(loc.slot, nullptr, nullptr, a6, true, t1);
+  return true;
+}
+
+bool TargetManager::getTargetTime(unsigned id, double& t) {
+  lock_guard<mutex> lg(target_lock_);
+  Loc loc;
+  if (!find(id, loc)) return false;
+  t = batches_[(size_t)loc.batch]->time(loc.slot);
+  return true;
+}
+
+int TargetManager::getTargetState(unsigned id, double* x, double* P) {
+  lock_guard<mutex> lg(target_lock_);
+  Loc loc;
+  if (!find(id, loc)) return 0;
+  Batch* b = batches_[(size_t)loc.batch].get();
+  b->get_state(&loc.slot, 1, x, P);
+  return b->n_state();
+}
+
+long long TargetManager::getNumberMeasurements(unsigned id) {
+  lock_guard<mutex> lg(target_lock_);
+  Loc loc;
+  if (find(id, loc)) return batches_[(size_t)loc.batch]->n_measurements(loc.slot);
+  std::cout << "Target(" << id << ") does not exist!" << std::endl;
+  return 0;
+}
+
+long TargetManager::updateBatch(const unsigned* ids, long n, double dt, const double* meas, const unsigned char* has_meas) {
+  lock_guard<mutex> lg(target_lock_);
+  const size_t nb = batches_.size();
+  std::vector<std::vector<int>> slots(nb);
+  std::vector<std::vector<long>> src(nb);
+  long done = 0;
+  for (long i = 0; i < n; ++i) {
+    Loc loc;
+    if (!find(ids[i], loc)) {
+      if (verbose_) std::cout << "Target(" << ids[i] << ") does not exist!" << std::endl;
+      continue;
+    }
+    slots[(size_t)loc.batch].push_back(loc.slot);
+    src[(size_t)loc.batch].push_back(i);
+    ++done;
+  }
+  for (size_t b = 0; b < nb; ++b) {
+    const long k = (long)slots[b].size();
+    if (!k) continue;
+    const bool contiguous = (k == n);  // single batch, every id known: rows already in order
+    if (contiguous) {
+      batches_[b]->step_indexed(slots[b].data(), k, dt, meas, has_meas);
+    } else {
+      std::vector<double> m2;
+      std::vector<unsigned char> h2;
+      if (meas) {
+        m2.resize((size_t)k * 7);
+        for (long j = 0; j < k; ++j) std::memcpy(&m2[(size_t)j * 7], meas + src[b][(size_t)j] * 7, sizeof(double) * 7);
+      }
+      if (has_meas) {
+        h2.resize((size_t)k);
+        for (long j = 0; j < k; ++j) h2[(size_t)j] = has_meas[src[b][(size_t)j]];
+      }
+      batches_[b]->step_indexed(slots[b].data(), k, dt, meas ? m2.data() : nullptr, has_meas ? h2.data() : nullptr);
+    }
+  }
+  return done;
+}
+
+long TargetManager::getPoseBatch(const unsigned* ids, long n, double* pose, double* twist, double* acc,
+                                 unsigned char* found, bool at_time, double t1) {
+  lock_guard<mutex> lg(target_lock_);
+  const size_t nb = batches_.size();
+  std::vector<std::vector<int>> slots(nb);
+  std::vector<std::vector<long>> src(nb);
+  long done = 0;
+  for (long i = 0; i < n; ++i) {
+    Loc loc;
+    const bool ok = find(ids[i], loc);
+    if (found) found[i] = ok ? 1 : 0;
+    if (!ok) continue;
+    slots[(size_t)loc.batch].push_back(loc.slot);
+    src[(size_t)loc.batch].push_back(i);
+    ++done;
+  }
+  for (size_t b = 0; b < nb; ++b) {
+    const long k = (long)slots[b].size();
+    if (!k) continue;
+    if (k == n) {
+      batches_[b]->outputs(slots[b].data(), k, pose, twist, acc, at_time, t1);
+      continue;
+    }
+    std::vector<double> p2(pose ? (size_t)k * 7 : 0), t2(twist ? (size_t)k * 6 : 0), a2(acc ? (size_t)k * 6 : 0);
+    batches_[b]->outputs(slots[b].data(), k, pose ? p2.data() : nullptr, twist ? t2.data() : nullptr,
+                         acc ? a2.data() : nullptr, at_time, t1);
+    for (long j = 0; j < k; ++j) {
+      const long i = src[b][(size_t)j];
+      if (pose) std::memcpy(pose + i * 7, &p2[(size_t)j * 7], sizeof(double) * 7);
+      if (twist) std::memcpy(twist + i * 6, &t2[(size_t)j * 6], sizeof(double) * 6);
+      if (acc) std::memcpy(acc + i * 6, &a2[(size_t)j * 6], sizeof(double) * 6);
+    }
+  }
+  return done;
+}
+
+long TargetManager::getStateBatch(const unsigned* ids, long n, double* x, double* P) {
+  lock_guard<mutex> lg(target_lock_);
+  if (n <= 0) return 0;
+  std::vector<int> slots((size_t)n);
+  int b0 = -1;
+  for (long i = 0; i < n; ++i) {
+    Loc loc;
+    if (!find(ids[i], loc)) return -1;
+    if (b0 < 0) b0 = loc.batch;
+    if (loc.batch != b0) return -2;  // all ids must belong to one batch (one state size)
+    slots[(size_t)i] = loc.slot;
+  }
+  batches_[(size_t)b0]->get_state(slots.data(), n, x, P);
+  return batches_[(size_t)b0]->n_state();
+}
+
+Batch* TargetManager::batchOfType(int type) {
+  for (auto& b : batches_)
+    if (b->type() == type) return b.get();
+  return nullptr;
+}
+
+void TargetManager::setStream(hipStream_t s) {
+  lock_guard<mutex> lg(target_lock_);
+  for (auto& b : batches_) { b->synchronize(); b->set_stream(s); }
+  stream_ = s;
+}
+
+void TargetManager::synchronize() {
+  for (auto& b : batches_) b->synchronize();
+}
+
+}  // namespace te

@@ -1,0 +1,106 @@
+// target_manager.hpp -- host-side mirror of the reference's TargetManager
+// (include/target_estimation/target_manager.hpp:33-203) over device-resident batches.
+//
+// Same method names, argument meaning, return values and messages as the reference; Eigen types
+// are replaced by raw arrays (the reference's Eigen-typed header needs Eigen3, absent here):
+//   Vector7d pose/meas  -> const double[7]  [x y z qx qy qz qw]   (target_manager.hpp:60)
+//   Vector6d twist/acc  -> const double[6]
+//   MatrixXd Q, R, P0   -> row-major const double[n*n] / [m*m]
+// Differences, all deliberate:
+//   * targets live in HBM, grouped into one Batch per (model, Q, R); the id -> (batch, slot)
+//     map is a std::map as in the reference, so enumeration stays ascending by id;
+//   * the per-target constructor dump (printInfo, target_interface.cpp:57-78) and the per-target
+//     type line (target_manager.cpp:161-173) are printed only when verbose (env
+//     TARGET_ESTIMATION_VERBOSE=1): a million-target init must not write a million dumps;
+//   * every filter step runs on the GPU; there is no CPU path.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "batch_store.hpp"
+
+namespace te {
+
+class TargetManager {
+ public:
+  typedef std::shared_ptr<TargetManager> Ptr;
+  // target_manager.hpp:38
+  enum target_t { ANGULAR_RATES = 0, ANGULAR_VELOCITIES, UNIFORM_ACCELERATION, UNIFORM_VELOCITY };
+
+  explicit TargetManager(int dtype = F64, int lanes_per_target = 0);
+  // throws const char* "TargetManager default constructor failed!" like target_manager.cpp:111-118
+  explicit TargetManager(const std::string& file, int dtype = F64, int lanes_per_target = 0);
+  virtual ~TargetManager();
+
+  // target_manager.cpp:135-142 (defaults from the YAML file; throws const char* if none loaded)
+  void init(unsigned id, double dt0, double t0, const double* p0, const double* v0 = nullptr, const double* a0 = nullptr);
+  // target_manager.cpp:144-179
+  void init(target_t type, unsigned id, double dt0, double t0, const double* Q, const double* R, const double* P0,
+            const double* p0, const double* v0 = nullptr, const double* a0 = nullptr);
+  // target_manager.cpp:181-188
+  void init(const std::string& file, unsigned id, double dt0, double t0, const double* p0, const double* v0 = nullptr,
+            const double* a0 = nullptr);
+  bool update(unsigned id, double dt, const double* meas);  // target_manager.cpp:190-202
+  bool update(unsigned id, double dt);                      // :204-218
+  virtual void update(double dt);                           // :220-225
+  bool erase(unsigned id);                                  // :227-241
+  bool getTargetPose(unsigned id, double* pose7);           // :252-261
+  bool getTargetTwist(unsigned id, double* twist6);         // :263-272
+  bool getTargetAcceleration(unsigned id, double* acc6);    // :274-283
+  long long getNumberMeasurements(unsigned id);             // :285-295
+  void log();                                               // :120-124 (rt_logger is out of scope: no-op)
+  std::vector<unsigned> getAvailableTargets();              // :126-133
+  bool selectTargetType(const std::string& type_str, target_t& type);  // :52-65
+
+  // TargetInterface getters reached through getTarget(id)-> in the reference
+  bool getTargetPoseAt(unsigned id, double t1, double* pose7);      // getEstimatedPose(t)
+  bool getTargetTwistAt(unsigned id, double t1, double* twist6);    // getEstimatedTwist(t)
+  bool getTargetAccelerationAt(unsigned id, double t1, double* a6); // getEstimatedAcceleration(t)
+  bool getTargetTime(unsigned id, double& t);                       // getTime()
+  // getTarget(id)->getEstimator()->getState()/getP() (kalman.hpp:69-89); x [n], P [n*n] row-major
+  int getTargetState(unsigned id, double* x, double* P);
+  bool hasTarget(unsigned id);
+  size_t size();
+
+  // ---- batched extension (not in the reference) ----------------------------------------------
+  long initBatch(const unsigned* ids, long n, double dt0, double t0, const double* p0, const double* v0, const double* a0);
+  long initBatch(target_t type, const unsigned* ids, long n, double dt0, double t0, const double* Q, const double* R,
+                 const double* P0, bool per_target_P0, const double* p0, const double* v0, const double* a0);
+  long updateBatch(const unsigned* ids, long n, double dt, const double* meas, const unsigned char* has_meas);
+  long getPoseBatch(const unsigned* ids, long n, double* pose, double* twist, double* acc, unsigned char* found,
+                    bool at_time = false, double t1 = 0.0);
+  long getStateBatch(const unsigned* ids, long n, double* x, double* P);
+
+  int numBatches() const { return (int)batches_.size(); }
+  Batch* batch(int i) { return batches_[(size_t)i].get(); }
+  Batch* batchOfType(int type);
+  void setStream(hipStream_t s);
+  void synchronize();
+  int dtype() const { return dtype_; }
+  bool defaultsLoaded() const { return default_values_loaded_; }
+  int defaultType() const { return (int)default_type_; }
+
+ protected:
+  struct Loc { int batch; int slot; };
+  bool loadYamlFile(const std::string& file, std::vector<double>& Q, std::vector<double>& R, std::vector<double>& P,
+                    target_t& type);  // target_manager.cpp:67-104
+  int findOrCreateBatch(int type, const double* Q, const double* R);
+  bool find(unsigned id, Loc& loc);
+
+  std::map<unsigned, Loc> targets_;
+  std::vector<std::unique_ptr<Batch>> batches_;
+  std::mutex target_lock_;
+  std::vector<double> default_Q_, default_P_, default_R_;
+  target_t default_type_ = UNIFORM_VELOCITY;
+  bool default_values_loaded_ = false;
+  int dtype_, lanes_;
+  hipStream_t stream_ = nullptr;
+  bool verbose_ = false;
+};
+
+}  // namespace te

@@ -1,0 +1,239 @@
+// target_manager_c.cpp -- extern "C" boundary over te::TargetManager.
+// The first ten functions are the reference's C wrapper (src/target_manager_c.cpp:15-76,
+// declared in include/target_estimation/target_manager_c.h:28-37); the rest is the batched
+// extension declared in include/target_estimation_amd/target_batch_c.h.
+#include <cstdio>
+#include <exception>
+#include <string>
+
+#include "../../include/target_estimation_amd/target_batch_c.h"
+#include "target_manager.hpp"
+
+using te::Batch;
+using te::TargetManager;
+
+namespace {
+thread_local std::string g_last_error;
+
+void set_error(const char* where, const char* what) {
+  g_last_error = std::string(where) + ": " + what;
+  std::fprintf(stderr, "[target_estimation_amd] %s\n", g_last_error.c_str());
+}
+
+// run f(); map the reference's thrown `const char*` / std::exception to an error code
+template <class F>
+int guarded(const char* where, F&& f) {
+  try {
+    f();
+    return 0;
+  } catch (const char* msg) {
+    set_error(where, msg);
+  } catch (const std::exception& e) {
+    set_error(where, e.what());
+  } catch (...) {
+    set_error(where, "unknown exception");
+  }
+  return -1;
+}
+
+inline TargetManager* M(const target_manager_c* self) { return (TargetManager*)self; }
+inline Batch* B(target_batch_c* b) { return (Batch*)b; }
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------- the reference's ten symbols
+target_manager_c* target_manager_new(const char* file) {
+  return target_manager_new_ex(file, TARGET_DTYPE_F64, 0);
+}
+
+void target_manager_init(const target_manager_c* self, const unsigned int id, const double dt0, double p0[], const double t0) {
+  guarded("target_manager_init", [&] { M(self)->init(id, dt0, t0, p0); });
+}
+
+void target_manager_update_meas(const target_manager_c* self, const unsigned int id, const double dt, double meas[]) {
+  guarded("target_manager_update_meas", [&] { M(self)->update(id, dt, meas); });
+}
+
+void target_manager_update(const target_manager_c* self, const unsigned int id, const double dt) {
+  guarded("target_manager_update", [&] { M(self)->update(id, dt); });
+}
+
+bool target_manager_get_est_pose(const target_manager_c* self, const unsigned int id, double pose[]) {
+  bool res = false;
+  guarded("target_manager_get_est_pose", [&] { res = M(self)->getTargetPose(id, pose); });
+  return res;
+}
+
+bool target_manager_get_est_twist(const target_manager_c* self, const unsigned int id, double twist[]) {
+  bool res = false;
+  guarded("target_manager_get_est_twist", [&] { res = M(self)->getTargetTwist(id, twist); });
+  return res;
+}
+
+bool target_manager_get_est_acceleration(const target_manager_c* self, const unsigned int id, double acceleration[]) {
+  bool res = false;
+  guarded("target_manager_get_est_acceleration", [&] { res = M(self)->getTargetAcceleration(id, acceleration); });
+  return res;
+}
+
+int target_manager_get_n_measurements(const target_manager_c* self, const unsigned int id) {
+  int n = 0;
+  guarded("target_manager_get_n_measurements", [&] { n = (int)M(self)->getNumberMeasurements(id); });
+  return n;
+}
+
+void target_manager_log(const target_manager_c* self) {
+  guarded("target_manager_log", [&] { M(self)->log(); });
+}
+
+void target_manager_delete(target_manager_c* self) {
+  guarded("target_manager_delete", [&] { delete M(self); });
+}
+
+// ---------------------------------------------------------------- batched extension
+target_manager_c* target_manager_new_ex(const char* file, int dtype, int lanes_per_target) {
+  TargetManager* m = nullptr;
+  guarded("target_manager_new", [&] {
+    m = file ? new TargetManager(std::string(file), dtype, lanes_per_target) : new TargetManager(dtype, lanes_per_target);
+  });
+  return (target_manager_c*)m;
+}
+
+int target_manager_set_stream(target_manager_c* self, void* hip_stream) {
+  return guarded("target_manager_set_stream", [&] { M(self)->setStream((hipStream_t)hip_stream); });
+}
+
+int target_manager_synchronize(target_manager_c* self) {
+  return guarded("target_manager_synchronize", [&] { M(self)->synchronize(); });
+}
+
+const char* target_manager_last_error(void) { return g_last_error.c_str(); }
+
+int target_manager_init_typed(target_manager_c* self, int type, unsigned int id, double dt0, double t0, const double* Q,
+                              const double* R, const double* P0, const double* p0, const double* v0, const double* a0) {
+  return guarded("target_manager_init_typed", [&] {
+    M(self)->init((TargetManager::target_t)type, id, dt0, t0, Q, R, P0, p0, v0, a0);
+  });
+}
+
+long target_manager_init_batch(target_manager_c* self, const unsigned int* ids, long n, double dt0, double t0,
+                               const double* p0, const double* v0, const double* a0) {
+  long k = -1;
+  guarded("target_manager_init_batch", [&] { k = M(self)->initBatch(ids, n, dt0, t0, p0, v0, a0); });
+  return k;
+}
+
+long target_manager_init_batch_typed(target_manager_c* self, int type, const unsigned int* ids, long n, double dt0,
+                                     double t0, const double* Q, const double* R, const double* P0, int per_target_P0,
+                                     const double* p0, const double* v0, const double* a0) {
+  long k = -1;
+  guarded("target_manager_init_batch_typed", [&] {
+    k = M(self)->initBatch((TargetManager::target_t)type, ids, n, dt0, t0, Q, R, P0, per_target_P0 != 0, p0, v0, a0);
+  });
+  return k;
+}
+
+int target_manager_erase(target_manager_c* self, unsigned int id) {
+  int r = -1;
+  guarded("target_manager_erase", [&] { r = M(self)->erase(id) ? 1 : 0; });
+  return r;
+}
+
+long target_manager_size(target_manager_c* self) {
+  long n = -1;
+  guarded("target_manager_size", [&] { n = (long)M(self)->size(); });
+  return n;
+}
+
+long target_manager_get_available_targets(target_manager_c* self, unsigned int* ids_out, long capacity) {
+  long n = -1;
+  guarded("target_manager_get_available_targets", [&] {
+    auto ids = M(self)->getAvailableTargets();
+    n = (long)ids.size();
+    for (long i = 0; i < n && i < capacity; ++i) ids_out[i] = ids[(size_t)i];
+  });
+  return n;
+}
+
+long target_manager_update_meas_batch(target_manager_c* self, const unsigned int* ids, long n, double dt,
+                                      const double* meas, const unsigned char* has_meas) {
+  long k = -1;
+  guarded("target_manager_update_meas_batch", [&] { k = M(self)->updateBatch(ids, n, dt, meas, has_meas); });
+  return k;
+}
+
+int target_manager_update_all(target_manager_c* self, double dt) {
+  return guarded("target_manager_update_all", [&] { M(self)->update(dt); });
+}
+
+long target_manager_get_est_batch(target_manager_c* self, const unsigned int* ids, long n, double* pose, double* twist,
+                                  double* acceleration, unsigned char* found) {
+  long k = -1;
+  guarded("target_manager_get_est_batch", [&] { k = M(self)->getPoseBatch(ids, n, pose, twist, acceleration, found); });
+  return k;
+}
+
+long target_manager_get_est_at_batch(target_manager_c* self, const unsigned int* ids, long n, double t1, double* pose,
+                                     double* twist, double* acceleration, unsigned char* found) {
+  long k = -1;
+  guarded("target_manager_get_est_at_batch", [&] {
+    k = M(self)->getPoseBatch(ids, n, pose, twist, acceleration, found, true, t1);
+  });
+  return k;
+}
+
+long target_manager_get_state_batch(target_manager_c* self, const unsigned int* ids, long n, double* x, double* P) {
+  long k = -1;
+  guarded("target_manager_get_state_batch", [&] { k = M(self)->getStateBatch(ids, n, x, P); });
+  return k;
+}
+
+int target_manager_get_time(target_manager_c* self, unsigned int id, double* t) {
+  int r = -1;
+  guarded("target_manager_get_time", [&] { r = M(self)->getTargetTime(id, *t) ? 0 : -2; });
+  return r;
+}
+
+int target_manager_num_batches(target_manager_c* self) { return M(self)->numBatches(); }
+
+target_batch_c* target_manager_get_batch(target_manager_c* self, int index) {
+  if (index < 0 || index >= M(self)->numBatches()) return nullptr;
+  return (target_batch_c*)M(self)->batch(index);
+}
+
+target_batch_c* target_manager_get_batch_of_type(target_manager_c* self, int type) {
+  return (target_batch_c*)M(self)->batchOfType(type);
+}
+
+long target_batch_size(target_batch_c* b) { return B(b)->size(); }
+int target_batch_type(target_batch_c* b) { return B(b)->type(); }
+int target_batch_dtype(target_batch_c* b) { return B(b)->dtype(); }
+int target_batch_state_dim(target_batch_c* b) { return B(b)->n_state(); }
+int target_batch_meas_dim(target_batch_c* b) { return B(b)->n_meas(); }
+int target_batch_lanes_per_target(target_batch_c* b) { return B(b)->layout().g; }
+long target_batch_algorithmic_bytes(target_batch_c* b) { return B(b)->algorithmic_bytes_per_cycle(); }
+double target_batch_resident_bytes_per_target(target_batch_c* b) {
+  return (double)B(b)->layout().tile_bytes / (double)B(b)->layout().tpw;
+}
+
+long target_batch_slot_ids(target_batch_c* b, unsigned int* ids_out, long capacity) {
+  const auto& ids = B(b)->slot_ids();
+  const long n = (long)ids.size();
+  for (long i = 0; i < n && i < capacity; ++i) ids_out[i] = ids[(size_t)i];
+  return n;
+}
+
+int target_batch_step(target_batch_c* b, double dt, const void* meas_dev, long ld, const unsigned char* has_meas_dev) {
+  return guarded("target_batch_step", [&] { B(b)->step_dense(dt, meas_dev, ld, has_meas_dev); });
+}
+
+int target_batch_get_est_dev(target_batch_c* b, double* pose_dev, double* twist_dev, double* acc_dev, int at_time, double t1) {
+  return guarded("target_batch_get_est_dev", [&] { B(b)->outputs_dev(pose_dev, twist_dev, acc_dev, at_time != 0, t1); });
+}
+
+int target_batch_pack_meas_dev(target_batch_c* b, const double* meas_aos_dev, long n, void* meas_soa_dev, long ld) {
+  return guarded("target_batch_pack_meas_dev", [&] { B(b)->pack_meas_dev(meas_aos_dev, n, meas_soa_dev, ld); });
+}
+
+}  // extern "C"

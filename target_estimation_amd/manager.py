@@ -1,0 +1,247 @@
+"""Python front-end over the C ABI (ctypes).  Mirrors the reference's TargetManager method names
+(include/target_estimation/target_manager.hpp:66-203); every numeric call goes through
+libtarget_estimation_amd.so and runs on the GPU.  torch is used only for device buffers/streams.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+ANGULAR_RATES, ANGULAR_VELOCITIES, UNIFORM_ACCELERATION, UNIFORM_VELOCITY = 0, 1, 2, 3
+MODEL_TYPES = {"angular_rates": 0, "angular_velocities": 1, "uniform_acceleration": 2, "uniform_velocity": 3}
+MODEL_DIMS = {0: (18, 6), 1: (12, 6), 2: (9, 3), 3: (6, 3)}
+DTYPES = {"f64": 0, "f32": 1}
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(capi.c_double_p)
+
+
+def _d(a, shape=None):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _ids(ids):
+    ids = np.ascontiguousarray(ids, dtype=np.uint32)
+    return ids, ids.ctypes.data_as(capi.c_uint_p)
+
+
+def _check(rc, what):
+    if rc is None or rc < 0:
+        raise RuntimeError("%s failed: %s" % (what, capi.last_error()))
+    return rc
+
+
+class Batch:
+    """All targets of one (model, Q, R) of a manager: the device-resident dense path."""
+
+    def __init__(self, lib, handle):
+        self._lib, self._h = lib, handle
+
+    size = property(lambda s: s._lib.target_batch_size(s._h))
+    type = property(lambda s: s._lib.target_batch_type(s._h))
+    dtype = property(lambda s: "f64" if s._lib.target_batch_dtype(s._h) == 0 else "f32")
+    state_dim = property(lambda s: s._lib.target_batch_state_dim(s._h))
+    meas_dim = property(lambda s: s._lib.target_batch_meas_dim(s._h))
+    lanes_per_target = property(lambda s: s._lib.target_batch_lanes_per_target(s._h))
+    algorithmic_bytes = property(lambda s: s._lib.target_batch_algorithmic_bytes(s._h))
+    resident_bytes_per_target = property(lambda s: s._lib.target_batch_resident_bytes_per_target(s._h))
+
+    def slot_ids(self):
+        n = self.size
+        out = np.empty(n, dtype=np.uint32)
+        self._lib.target_batch_slot_ids(self._h, out.ctypes.data_as(capi.c_uint_p), n)
+        return out
+
+    def torch_dtype(self):
+        import torch
+        return torch.float64 if self.dtype == "f64" else torch.float32
+
+    def step(self, dt, meas=None, has_meas=None):
+        """One tick over every target.  meas: CUDA tensor [7, ld] (SoA, batch precision) or None
+        (predict only); has_meas: CUDA uint8 tensor [size] or None.  Asynchronous."""
+        mp, ld, hp = None, 0, None
+        if meas is not None:
+            assert meas.is_cuda and meas.dim() == 2 and meas.shape[0] == 7 and meas.stride(1) == 1
+            assert meas.dtype == self.torch_dtype(), (meas.dtype, self.dtype)
+            assert meas.shape[1] >= self.size
+            mp, ld = meas.data_ptr(), meas.stride(0)
+        if has_meas is not None:
+            assert has_meas.is_cuda and has_meas.numel() >= self.size and has_meas.element_size() == 1
+            hp = has_meas.data_ptr()
+        _check(self._lib.target_batch_step(self._h, float(dt), mp, ld, hp), "target_batch_step")
+
+    def get_est(self, pose=True, twist=True, acc=True, t1=None):
+        """Derived outputs of every slot as CUDA double tensors ([size,7], [size,6], [size,6])."""
+        import torch
+        n = self.size
+        mk = lambda w, on: torch.empty((n, w), dtype=torch.float64, device="cuda") if on else None  # noqa: E731
+        p, t, a = mk(7, pose), mk(6, twist), mk(6, acc)
+        ptr = lambda x: None if x is None else x.data_ptr()  # noqa: E731
+        _check(self._lib.target_batch_get_est_dev(self._h, ptr(p), ptr(t), ptr(a), 0 if t1 is None else 1,
+                                                   0.0 if t1 is None else float(t1)), "target_batch_get_est_dev")
+        return p, t, a
+
+    def pack_meas(self, meas_aos, out=None):
+        """CUDA double [n,7] (the reference's row layout) -> SoA [7,n] in the batch precision."""
+        import torch
+        n = meas_aos.shape[0]
+        assert meas_aos.is_cuda and meas_aos.dtype == torch.float64 and meas_aos.is_contiguous()
+        if out is None:
+            out = torch.empty((7, n), dtype=self.torch_dtype(), device="cuda")
+        _check(self._lib.target_batch_pack_meas_dev(self._h, meas_aos.data_ptr(), n, out.data_ptr(), out.stride(0)),
+               "target_batch_pack_meas_dev")
+        return out
+
+
+class TargetManager:
+    """ctypes mirror of the reference TargetManager; dtype 'f64' (reference precision) or 'f32'."""
+
+    def __init__(self, file=None, dtype="f64", lanes_per_target=0):
+        self._lib = capi.lib()
+        f = None if file is None else str(file).encode()
+        self._h = self._lib.target_manager_new_ex(f, DTYPES[dtype], int(lanes_per_target))
+        if not self._h:
+            raise RuntimeError("target_manager_new failed: %s" % capi.last_error())
+        self.dtype = dtype
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.target_manager_delete(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def handle(self):
+        return self._h
+
+    # ---- the reference's per-target calls ---------------------------------------------------
+    def init(self, id, dt0, t0, p0, v0=None, a0=None, type=None, Q=None, R=None, P0=None):
+        p0 = _d(p0, (7,))
+        if type is None:
+            assert v0 is None and a0 is None, "the C boundary's init takes a pose only (target_manager_c.h:29)"
+            self._lib.target_manager_init(self._h, int(id), float(dt0), _dp(p0), float(t0))
+            return
+        n, m = MODEL_DIMS[int(type)]
+        Q, R, P0 = _d(Q, (n, n)), _d(R, (m, m)), _d(P0, (n, n))
+        v0, a0 = _d(v0, (6,)), _d(a0, (6,))
+        _check(self._lib.target_manager_init_typed(self._h, int(type), int(id), float(dt0), float(t0), _dp(Q), _dp(R),
+                                                    _dp(P0), _dp(p0), _dp(v0), _dp(a0)), "target_manager_init_typed")
+
+    def update(self, id, dt, meas=None):
+        if meas is None:
+            self._lib.target_manager_update(self._h, int(id), float(dt))
+        else:
+            meas = _d(meas, (7,))
+            self._lib.target_manager_update_meas(self._h, int(id), float(dt), _dp(meas))
+
+    def update_all(self, dt):
+        _check(self._lib.target_manager_update_all(self._h, float(dt)), "target_manager_update_all")
+
+    def erase(self, id):
+        return bool(_check(self._lib.target_manager_erase(self._h, int(id)), "target_manager_erase"))
+
+    def _get1(self, fn, id, w):
+        out = np.full(w, np.nan)
+        ok = fn(self._h, int(id), _dp(out))
+        return bool(ok), out
+
+    def getTargetPose(self, id):
+        return self._get1(self._lib.target_manager_get_est_pose, id, 7)
+
+    def getTargetTwist(self, id):
+        return self._get1(self._lib.target_manager_get_est_twist, id, 6)
+
+    def getTargetAcceleration(self, id):
+        return self._get1(self._lib.target_manager_get_est_acceleration, id, 6)
+
+    def getNumberMeasurements(self, id):
+        return self._lib.target_manager_get_n_measurements(self._h, int(id))
+
+    def getAvailableTargets(self):
+        n = self._lib.target_manager_size(self._h)
+        out = np.empty(max(n, 1), dtype=np.uint32)
+        n = self._lib.target_manager_get_available_targets(self._h, out.ctypes.data_as(capi.c_uint_p), n)
+        return out[:n]
+
+    def getTime(self, id):
+        t = C.c_double()
+        rc = self._lib.target_manager_get_time(self._h, int(id), C.byref(t))
+        return t.value if rc == 0 else None
+
+    def log(self):
+        self._lib.target_manager_log(self._h)
+
+    def size(self):
+        return self._lib.target_manager_size(self._h)
+
+    def synchronize(self):
+        _check(self._lib.target_manager_synchronize(self._h), "target_manager_synchronize")
+
+    def set_stream(self, stream_ptr):
+        _check(self._lib.target_manager_set_stream(self._h, stream_ptr), "target_manager_set_stream")
+
+    # ---- batched extension ---------------------------------------------------------------------
+    def init_batch(self, ids, dt0, t0, p0, v0=None, a0=None, type=None, Q=None, R=None, P0=None):
+        ids, idp = _ids(ids)
+        n = len(ids)
+        p0, v0, a0 = _d(p0, (n, 7)), _d(v0, (n, 6)), _d(a0, (n, 6))
+        if type is None:
+            return _check(self._lib.target_manager_init_batch(self._h, idp, n, float(dt0), float(t0), _dp(p0), _dp(v0),
+                                                              _dp(a0)), "target_manager_init_batch")
+        ns, m = MODEL_DIMS[int(type)]
+        Q, R = _d(Q, (ns, ns)), _d(R, (m, m))
+        P0 = _d(P0)
+        per = 1 if P0.ndim == 3 else 0
+        return _check(self._lib.target_manager_init_batch_typed(
+            self._h, int(type), idp, n, float(dt0), float(t0), _dp(Q), _dp(R), _dp(np.ascontiguousarray(P0)), per,
+            _dp(p0), _dp(v0), _dp(a0)), "target_manager_init_batch_typed")
+
+    def update_batch(self, ids, dt, meas=None, has_meas=None):
+        ids, idp = _ids(ids)
+        n = len(ids)
+        meas = _d(meas, (n, 7))
+        hp = None
+        if has_meas is not None:
+            has_meas = np.ascontiguousarray(has_meas, dtype=np.uint8)
+            hp = has_meas.ctypes.data_as(capi.c_ubyte_p)
+        return _check(self._lib.target_manager_update_meas_batch(self._h, idp, n, float(dt), _dp(meas), hp),
+                      "target_manager_update_meas_batch")
+
+    def get_est_batch(self, ids, t1=None):
+        ids, idp = _ids(ids)
+        n = len(ids)
+        pose, twist, acc = np.full((n, 7), np.nan), np.full((n, 6), np.nan), np.full((n, 6), np.nan)
+        found = np.zeros(n, dtype=np.uint8)
+        fp = found.ctypes.data_as(capi.c_ubyte_p)
+        if t1 is None:
+            _check(self._lib.target_manager_get_est_batch(self._h, idp, n, _dp(pose), _dp(twist), _dp(acc), fp),
+                   "target_manager_get_est_batch")
+        else:
+            _check(self._lib.target_manager_get_est_at_batch(self._h, idp, n, float(t1), _dp(pose), _dp(twist), _dp(acc),
+                                                             fp), "target_manager_get_est_at_batch")
+        return pose, twist, acc, found.astype(bool)
+
+    def get_state_batch(self, ids):
+        ids, idp = _ids(ids)
+        n = len(ids)
+        x = np.empty((n, 18)); P = np.empty((n, 18 * 18))
+        ns = _check(self._lib.target_manager_get_state_batch(self._h, idp, n, _dp(x), _dp(P)),
+                    "target_manager_get_state_batch")
+        return (x.reshape(-1)[:n * ns].reshape(n, ns).copy(),
+                P.reshape(-1)[:n * ns * ns].reshape(n, ns, ns).copy())
+
+    def batches(self):
+        return [Batch(self._lib, self._lib.target_manager_get_batch(self._h, i))
+                for i in range(self._lib.target_manager_num_batches(self._h))]
+
+    def batch_of_type(self, type):
+        h = self._lib.target_manager_get_batch_of_type(self._h, int(type))
+        return Batch(self._lib, h) if h else None
