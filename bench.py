@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- predict+update cycles/s of the batched Kalman path on MI355X.
+
+One "step" = one tick = one pass of the hot path (predict + measurement update of every target)
+over one batch of synthetic measurements already resident in HBM.  Default workload: BASELINE.json
+configs[1] (10 000 uniform-velocity targets, fp64, one GPU).  Other workloads via --workload.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4ar|cfg4av|uv1m|...]
+
+For N > 1 the driver launches one rank per GPU with torch.distributed.run; targets are independent,
+so each rank owns its own shard (weak scaling: the per-GPU workload is fixed) and there is no
+data-path collective.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: (description, model, dtype, targets per GPU, seed)
+    "cfg2": ("10000 targets, uniform-velocity model, fp64 (BASELINE.json configs[1])", "uniform_velocity", "f64", 10_000, 20240002),
+    "cfg3": ("100000 targets, uniform-acceleration model, fp32 (configs[2])", "uniform_acceleration", "f32", 100_000, 20240003),
+    "cfg4ar": ("angular-rates half of configs[3], 62500 targets per GPU, fp32", "angular_rates", "f32", 62_500, 20240004),
+    "cfg4av": ("angular-velocities half of configs[3], 62500 targets per GPU, fp32", "angular_velocities", "f32", 62_500, 20240004),
+    "uv1m": ("1000000 targets, uniform-velocity model, fp64", "uniform_velocity", "f64", 1_000_000, 20240012),
+    "ua1m": ("1000000 targets, uniform-acceleration model, fp32", "uniform_acceleration", "f32", 1_000_000, 20240013),
+    "ar1m": ("1000000 targets, angular-rates model, fp32", "angular_rates", "f32", 1_000_000, 20240014),
+    "av1m": ("1000000 targets, angular-velocities model, fp32", "angular_velocities", "f32", 1_000_000, 20240015),
+    "ar1m64": ("1000000 targets, angular-rates model, fp64", "angular_rates", "f64", 1_000_000, 20240016),
+    "av1m64": ("1000000 targets, angular-velocities model, fp64", "angular_velocities", "f64", 1_000_000, 20240017),
+}
+
+
+def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None, rank=0, world=1, stream_ticks=32):
+    from target_estimation_amd.streams import make_stream
+    desc, model, dtype, n_targets, seed = WORKLOADS[name]
+    if targets:
+        n_targets = targets
+    path = os.path.join(ROOT, "models", "model_%s_params.yaml" % model)
+    mgr = te.TargetManager(path, dtype=dtype, lanes_per_target=lanes)
+    mgr.set_stream(torch.cuda.current_stream().cuda_stream)
+    mtype = te.MODEL_TYPES[model]
+    dt = 1.0 / 250.0
+    ticks = min(stream_ticks, steps + warmup)
+    st = make_stream(mtype, n_targets, ticks, dt, seed + 1000 * rank)
+    import numpy as np
+    ids = np.arange(n_targets, dtype=np.uint32) + rank * n_targets  # global ids: rank-contiguous shards
+    mgr.init_batch(ids, dt, 0.0, st["p0"].cpu().numpy())
+    b = mgr.batches()[0]
+    meas = st["meas"].to(b.torch_dtype()).contiguous()   # [ticks, 7, N] in the batch precision
+    torch.cuda.synchronize()
+
+    def tick(s):
+        b.step(dt, meas[s % ticks])
+
+    for s in range(warmup):
+        tick(s)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for s in range(steps):
+        tick(warmup + s)
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    dev_ms = ev0.elapsed_time(ev1)
+    # sanity: the state is finite after the run
+    x, P = mgr.get_state_batch(ids[:64])
+    assert np.isfinite(x).all() and np.isfinite(P).all()
+    launch_s = dev_ms * 1e-3 / steps
+    alg_bytes = b.algorithmic_bytes * n_targets
+    res = dict(
+        name=name, desc=desc, model=model, dtype=dtype, targets_per_gpu=n_targets,
+        lanes_per_target=b.lanes_per_target, elapsed_s=elapsed, ms_per_step=elapsed * 1e3 / steps,
+        cycles_per_s=n_targets * world * steps / elapsed,
+        device_ms_per_launch=launch_s * 1e3,
+        algorithmic_bytes_per_cycle=b.algorithmic_bytes, algorithmic_bytes_per_launch=alg_bytes,
+        achieved_gbs=alg_bytes / launch_s / 1e9,
+        resident_bytes_per_target=b.resident_bytes_per_target)
+    res["_mgr"] = (mgr, b, st, ids, dt)
+    return res
+
+
+def host_threads(omp_max):
+    """Threads the CPU baseline may use: the smallest of OpenMP's default, the affinity mask and
+    the cgroup CPU quota (a GPU box hands one GPU a 16-CPU share of a larger host)."""
+    n = omp_max
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    env = os.environ.get("TE_CPU_THREADS")
+    if env:
+        n = int(env)
+    return max(1, n)
+
+
+def cpu_baseline(name, targets=None, budget_s=6.0):
+    """The CPU oracle (oracle/, the 'port' of the reference's Eigen path) with OpenMP over targets
+    on this box's host cores, on a bounded sample of the same workload."""
+    import numpy as np
+    import oracle
+    desc, model, dtype, n_targets, seed = WORKLOADS[name]
+    if targets:
+        n_targets = targets
+    n_cpu = min(n_targets, 20000)
+    m = oracle.load_model_yaml(os.path.join(ROOT, "models", "model_%s_params.yaml" % model))
+    rng = np.random.default_rng(seed)
+    p0 = np.concatenate([rng.uniform(-10, 10, (n_cpu, 3)), np.tile([0, 0, 0, 1.0], (n_cpu, 1))], 1)
+    dt = 1.0 / 250.0
+    ob = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], p0, dt, dtype=dtype, fast=True)
+    threads = host_threads(oracle.load(True).orc_max_threads())
+    meas = p0.copy()
+    ob.step(dt, meas, nthreads=threads)  # warm
+    t0 = time.perf_counter()
+    ticks = 0
+    while True:
+        meas[:, :3] += 0.004 + rng.normal(0, 0.01, (n_cpu, 3))
+        ob.step(dt, meas, nthreads=threads)
+        ticks += 1
+        if time.perf_counter() - t0 > budget_s and ticks >= 5:
+            break
+    el = time.perf_counter() - t0
+    return dict(value=n_cpu * ticks / el, unit="cycles/s", cores=int(threads), kind="port",
+                sample="%d %s targets x %d ticks (%s, OpenMP static over targets, %.1f s)" % (n_cpu, model, ticks, dtype, el))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per target (0 = tuned default)")
+    ap.add_argument("--targets", type=int, default=0, help="override targets per GPU")
+    ap.add_argument("--extra", default="uv1m,ar1m,av1m,ua1m", help="comma list of extra workloads reported under 'extra' (N=1 only; '' = none)")
+    ap.add_argument("--extra-steps", type=int, default=50)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist_mod.init_process_group("nccl")
+        dist = dist_mod
+    import target_estimation_amd as te
+
+    res = run_workload(te, torch, args.workload, args.steps, args.warmup, args.lanes, args.targets or None,
+                       dist, rank, world)
+    mgr = res.pop("_mgr")
+    out = {
+        "metric": "KF predict+update cycles/sec over N targets",
+        "value": res["cycles_per_s"], "unit": "cycles/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": res["dtype"], "data": "synthetic",
+        "config": {"workload": res["desc"], "name": res["name"], "model": res["model"],
+                   "targets_per_gpu": res["targets_per_gpu"], "targets_total": res["targets_per_gpu"] * world,
+                   "lanes_per_target": res["lanes_per_target"], "dt": 0.004,
+                   "sharding": "contiguous id ranges per rank, no data-path collective"},
+        "roofline": {"bound": "hbm", "achieved": res["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": res["achieved_gbs"] / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "kf_step_kernel<%s,%s,G=%d>" % (res["model"], res["dtype"], res["lanes_per_target"]),
+                     "algorithmic_bytes_per_cycle": res["algorithmic_bytes_per_cycle"],
+                     "algorithmic_bytes_per_launch": res["algorithmic_bytes_per_launch"],
+                     "device_ms_per_launch": res["device_ms_per_launch"]},
+    }
+    del mgr
+    if world == 1 and rank == 0:
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.targets or None)
+        extras = []
+        for name in [e for e in args.extra.split(",") if e]:
+            if name == args.workload:
+                continue
+            r = run_workload(te, torch, name, args.extra_steps, 10, 0)
+            r.pop("_mgr")
+            extras.append({k: r[k] for k in ("name", "desc", "dtype", "targets_per_gpu", "lanes_per_target", "cycles_per_s",
+                                            "ms_per_step", "device_ms_per_launch", "achieved_gbs",
+                                            "algorithmic_bytes_per_cycle")} | {"roofline_frac": r["achieved_gbs"] / HBM_PEAK_GBS})
+            torch.cuda.empty_cache()
+        out["extra"] = extras
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

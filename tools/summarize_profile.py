@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Summarise a tools/profile.sh output directory into a small text file for profiles/.
+
+Groups dispatches by (kernel, grid size) so that workloads sharing a kernel template are kept
+apart, reports count / avg / min / max duration from --kernel-trace, and HBM bytes per launch from
+the FETCH_SIZE / WRITE_SIZE passes with the gfx950 corrections of MI355X_MICROARCH.md ('HBM':
+counters are in units of 1024 B; FETCH_SIZE reads exactly half of a wide coalesced stream's
+bytes, so it is doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores).
+usage: tools/summarize_profile.py gpurun_out/prof_<tag> [kernel-substring]
+"""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"\(.*", "", name)
+    return name.replace("void ", "").replace("te::", "")
+
+
+def load_trace(path):
+    groups = defaultdict(list)
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            g = int(r.get("Grid_Size_X") or r.get("Grid_Size") or 0)
+            groups[(short(r["Kernel_Name"]), g)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    return groups
+
+
+def load_counter(path):
+    groups = defaultdict(list)
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            groups[(short(r["Kernel_Name"]), int(r["Grid_Size"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+    return groups
+
+
+def main():
+    d = sys.argv[1]
+    flt = sys.argv[2] if len(sys.argv) > 2 else "kf_step"
+    trace = load_trace(glob.glob(os.path.join(d, "trace", "*kernel_trace.csv"))[0])
+    counters = {}
+    for sub in ("fetch", "write"):
+        files = glob.glob(os.path.join(d, sub, "*counter_collection.csv"))
+        if files:
+            counters.update(load_counter(files[0]))
+    print("# rocprofv3 summary of %s (kernels matching '%s')" % (os.path.basename(d.rstrip("/")), flt))
+    print("# durations: --kernel-trace; bytes: --pmc FETCH_SIZE / WRITE_SIZE (separate passes)")
+    print("# hbm_read = 2 * FETCH_SIZE * 1024 (gfx950 wide-stream correction), hbm_write = WRITE_SIZE * 1024")
+    print("%-52s %9s %6s %10s %10s %10s %12s %12s" % ("kernel", "grid", "calls", "avg_us", "min_us", "max_us", "hbm_rd_MB", "hbm_wr_MB"))
+    for (k, g), durs in sorted(trace.items(), key=lambda kv: -sum(kv[1])):
+        if flt not in k:
+            continue
+        fs = counters.get((k, g, "FETCH_SIZE"))
+        ws = counters.get((k, g, "WRITE_SIZE"))
+        rd = "%12.3f" % (2 * 1024 * sum(fs) / len(fs) / 1e6) if fs else "%12s" % "-"
+        wr = "%12.3f" % (1024 * sum(ws) / len(ws) / 1e6) if ws else "%12s" % "-"
+        print("%-52s %9d %6d %10.2f %10.2f %10.2f %s %s" % (k[:52], g, len(durs), sum(durs) / len(durs) / 1e3,
+                                                         min(durs) / 1e3, max(durs) / 1e3, rd, wr))
+    for tag in ("trace", "fetch", "write"):
+        p = os.path.join(d, "bench_%s.json" % tag)
+        if os.path.exists(p):
+            print("# bench line under the %s pass: %s" % (tag, open(p).read().strip()[:1500]))
+
+
+if __name__ == "__main__":
+    main()
