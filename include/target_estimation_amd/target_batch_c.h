@@ -78,6 +78,25 @@ long target_manager_get_state_batch(target_manager_c* self, const unsigned int* 
 /* TargetInterface::getTime() */
 int target_manager_get_time(target_manager_c* self, unsigned int id, double* t);
 
+/* ---- sphere intersection (IntersectionSolver, src/intersection_solver.cpp:42-104) -------------- */
+/* Time from t1 (absolute) to the first crossing of the sphere |p - origin| = radius along the
+ * extrapolated trajectory p + v d + a d^2/2 (smallest real root of the quartic; -1 if none, if
+ * it is negative, if the target has zero acceleration -- uniform_velocity and angular_velocities
+ * targets never intersect in the reference -- or if the id is unknown).
+ * Replaces IntersectionSolver::getIntersectionTimeWithSphere, intersection_solver.cpp:42-89. */
+double target_manager_get_intersection_time_with_sphere(target_manager_c* self, unsigned int id, double t1,
+                                                         const double* origin, double radius);
+/* Pose at t1 + delta ([0 0 0 0 0 0 1] if none); returns whether an intersection exists.  Replaces
+ * IntersectionSolver::getIntersectionPoseWithSphere, intersection_solver.cpp:91-104, WITHOUT its
+ * moving-average convergence gate (:105-120; SURVEY 8f "next").  delta may be NULL. */
+bool target_manager_get_intersection_pose_with_sphere(target_manager_c* self, unsigned int id, double t1,
+                                                      const double* origin, double radius, double* pose,
+                                                      double* delta);
+/* the same for n ids: delta [n], pose [n][7] or NULL, found [n] or NULL */
+long target_manager_intersect_sphere_batch(target_manager_c* self, const unsigned int* ids, long n, double t1,
+                                           const double* origin, double radius, double* delta, double* pose,
+                                           unsigned char* found);
+
 /* ---- device-resident dense path ---------------------------------------------------------- */
 int target_manager_num_batches(target_manager_c* self);
 target_batch_c* target_manager_get_batch(target_manager_c* self, int index);
@@ -102,6 +121,11 @@ int target_batch_step(target_batch_c* b, double dt, const void* meas_dev, long l
 /* derived outputs of every slot into device arrays of doubles ([size][7], [size][6], [size][6];
  * any may be NULL); at_time != 0 extrapolates to t1 */
 int target_batch_get_est_dev(target_batch_c* b, double* pose_dev, double* twist_dev, double* acc_dev, int at_time, double t1);
+/* every slot of the batch: delta_dev [size], pose_dev [size][7] or NULL (device doubles); a NaN t1
+ * means "each target's own current time" (the per-tick fused query of BASELINE.json configs[4]);
+ * origin is a host array of 3 */
+int target_batch_intersect_sphere_dev(target_batch_c* b, double t1, const double* origin, double radius,
+                                      double* delta_dev, double* pose_dev);
 /* AoS doubles [n][7] (host layout of the reference) -> SoA [7][ld] in the batch precision, on device */
 int target_batch_pack_meas_dev(target_batch_c* b, const double* meas_aos_dev, long n, void* meas_soa_dev, long ld);
 

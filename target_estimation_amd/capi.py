@@ -48,6 +48,12 @@ SIGNATURES = {
                                                    c_double_p, c_ubyte_p]),
     "target_manager_get_state_batch": (C.c_long, [C.c_void_p, c_uint_p, C.c_long, c_double_p, c_double_p]),
     "target_manager_get_time": (C.c_int, [C.c_void_p, C.c_uint, c_double_p]),
+    "target_manager_get_intersection_time_with_sphere": (C.c_double, [C.c_void_p, C.c_uint, C.c_double, c_double_p, C.c_double]),
+    "target_manager_get_intersection_pose_with_sphere": (C.c_bool, [C.c_void_p, C.c_uint, C.c_double, c_double_p, C.c_double,
+                                                                    c_double_p, c_double_p]),
+    "target_manager_intersect_sphere_batch": (C.c_long, [C.c_void_p, c_uint_p, C.c_long, C.c_double, c_double_p, C.c_double,
+                                                         c_double_p, c_double_p, c_ubyte_p]),
+    "target_batch_intersect_sphere_dev": (C.c_int, [C.c_void_p, C.c_double, c_double_p, C.c_double, C.c_void_p, C.c_void_p]),
     "target_manager_num_batches": (C.c_int, [C.c_void_p]),
     "target_manager_get_batch": (C.c_void_p, [C.c_void_p, C.c_int]),
     "target_manager_get_batch_of_type": (C.c_void_p, [C.c_void_p, C.c_int]),

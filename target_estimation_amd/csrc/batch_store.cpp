@@ -246,6 +246,32 @@ void Batch::outputs_one(long slot, double* pose, double* twist, double* acc, boo
   if (acc) std::memcpy(acc, h_ring_out_ + 13, sizeof(double) * 6);
 }
 
+void Batch::intersect(const int* slots, long n, double t1, const double* origin, double radius, double* delta, double* pose) {
+  if (n <= 0) return;
+  stage_reserve(n);
+  if (slots) upload_slots(slots, n);
+  IntersectArgs a;
+  a.rec = d_rec_; a.idx = slots ? d_idx_ : nullptr; a.n = n; a.t1 = t1;
+  a.origin[0] = origin[0]; a.origin[1] = origin[1]; a.origin[2] = origin[2]; a.radius = radius;
+  a.t_acc = t_acc_; a.t_base = d_tbase_;
+  a.delta = d_aos_; a.pose = pose ? d_aos_ + n : nullptr;
+  ops_->intersect(a, stream_);
+  TE_HIP_CHECK(hipGetLastError());
+  TE_HIP_CHECK(hipMemcpyAsync(delta, a.delta, sizeof(double) * n, hipMemcpyDeviceToHost, stream_));
+  if (pose) TE_HIP_CHECK(hipMemcpyAsync(pose, a.pose, sizeof(double) * 7 * n, hipMemcpyDeviceToHost, stream_));
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Batch::intersect_dev(double t1, const double* origin, double radius, double* delta_dev, double* pose_dev) {
+  if (n_ == 0) return;
+  IntersectArgs a;
+  a.rec = d_rec_; a.idx = nullptr; a.n = n_; a.t1 = t1;
+  a.origin[0] = origin[0]; a.origin[1] = origin[1]; a.origin[2] = origin[2]; a.radius = radius;
+  a.t_acc = t_acc_; a.t_base = d_tbase_; a.delta = delta_dev; a.pose = pose_dev;
+  ops_->intersect(a, stream_);
+  TE_HIP_CHECK(hipGetLastError());
+}
+
 void Batch::pack_meas_dev(const double* aos_dev, long n, void* soa_dev, long ld) {
   ops_->pack_meas(aos_dev, n, soa_dev, ld, stream_);
   TE_HIP_CHECK(hipGetLastError());

@@ -57,6 +57,12 @@ class Batch {
   // AoS doubles [n][7] on device -> SoA [7][ld] in the batch precision on device
   void pack_meas_dev(const double* aos_dev, long n, void* soa_dev, long ld);
 
+  // IntersectionSolver::getIntersectionTime/PoseWithSphere (src/intersection_solver.cpp:42-104)
+  // for the listed slots (host arrays; slots == null: all) or, _dev, every slot to device arrays.
+  // t1 is absolute; NaN means each target's own current time.
+  void intersect(const int* slots, long n, double t1, const double* origin, double radius, double* delta, double* pose);
+  void intersect_dev(double t1, const double* origin, double radius, double* delta_dev, double* pose_dev);
+
   void get_state(const int* slots, long n, double* x, double* P);
   void set_state(const int* slots, long n, const double* x, const double* P, const double* unwrap);
   long long n_measurements(long slot);

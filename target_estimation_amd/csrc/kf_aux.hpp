@@ -5,6 +5,7 @@
 
 #include "te_device_math.hpp"
 #include "te_layout.hpp"
+#include "te_quartic.hpp"
 
 namespace te {
 
@@ -259,6 +260,59 @@ __global__ void outputs_kernel(const OutArgs a) {
   if (a.pose) for (int c = 0; c < 7; ++c) a.pose[e * 7 + c] = (double)pose7[c];
   if (a.twist) for (int c = 0; c < 6; ++c) a.twist[e * 6 + c] = (double)twist6[c];
   if (a.acc) for (int c = 0; c < 6; ++c) a.acc[e * 6 + c] = (double)acc6[c];
+}
+
+struct IntersectArgs {
+  char* rec;
+  const int* idx;     // null: dense slots 0..n-1
+  long n;
+  double t1;          // absolute query time; NaN = each target's own time (t1 = t_)
+  double origin[3];
+  double radius;
+  double t_acc;
+  const double* t_base;
+  double* delta;      // [n]: time to the first intersection after t1, or -1
+  double* pose;       // [n][7] pose at t1 + delta (initPose if none), or null
+};
+
+// IntersectionSolver::getIntersectionTimeWithSphere / getIntersectionPoseWithSphere without the
+// moving-average convergence gate (src/intersection_solver.cpp:42-104): quartic in delta from the
+// extrapolated (p, v, a) at t1, smallest real root, pose at t1 + delta.
+template <class M, typename T, int G>
+__global__ void intersect_kernel(const IntersectArgs a) {
+  using C = Cfg<M, T, G>;
+  constexpr int N = C::N;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.n) return;
+  const long slot = a.idx ? (long)a.idx[e] : e;
+  T x[N];
+#pragma unroll
+  for (int r = 0; r < N; ++r) x[r] = *state_ptr<C, T>(a.rec, slot, r, N);
+  const double t = a.t_base[slot] + a.t_acc;
+  const double t1 = (a.t1 != a.t1) ? t : a.t1;
+  T pose7[7], twist6[6], acc6[6];
+  derive_outputs<M, T>(x, true, (T)(t1 - t), pose7, twist6, acc6);
+  const double px = (double)pose7[0] - a.origin[0], py = (double)pose7[1] - a.origin[1], pz = (double)pose7[2] - a.origin[2];
+  const double vx = (double)twist6[0], vy = (double)twist6[1], vz = (double)twist6[2];
+  const double ax = (double)acc6[0], ay = (double)acc6[1], az = (double)acc6[2];
+  double c[5];
+  c[4] = 0.25 * (ax * ax + ay * ay + az * az);
+  c[3] = vx * ax + vy * ay + vz * az;
+  c[2] = vx * vx + vy * vy + vz * vz + px * ax + py * ay + pz * az;
+  c[1] = 2 * (px * vx + py * vy + pz * vz);
+  c[0] = px * px + py * py + pz * pz - a.radius * a.radius;
+  double d = lowest_real_root_quartic(c);
+  if (d < 0) d = -1.0;
+  a.delta[e] = d;
+  if (a.pose) {
+    double out[7] = {0, 0, 0, 0, 0, 0, 1};
+    if (d > -1) {
+      derive_outputs<M, T>(x, true, (T)((d + t1) - t), pose7, twist6, acc6);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) out[k] = (double)pose7[k];
+    }
+    for (int k = 0; k < 7; ++k) a.pose[e * 7 + k] = out[k];
+  }
 }
 
 }  // namespace te

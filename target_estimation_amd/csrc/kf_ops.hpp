@@ -33,6 +33,7 @@ struct Ops {
   void (*move_record)(char* rec, long src, long dst, double* t_base, int* nm_base, hipStream_t);
   void (*outputs)(const OutArgs&, hipStream_t);
   void (*pack_meas)(const double* aos, long n, void* soa, long ld, hipStream_t);
+  void (*intersect)(const IntersectArgs&, hipStream_t);
 };
 
 // g == 0 selects the default lanes-per-target of the (model, precision); nullptr if unsupported

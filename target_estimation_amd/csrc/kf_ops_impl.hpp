@@ -49,10 +49,14 @@ struct OpsImpl {
     if (n <= 0) return;
     hipLaunchKernelGGL((pack_meas_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, aos, n, static_cast<T*>(soa), ld);
   }
+  static void intersect(const IntersectArgs& a, hipStream_t s) {
+    if (a.n <= 0) return;
+    hipLaunchKernelGGL((intersect_kernel<M, T, G>), dim3((unsigned)((a.n + 63) / 64)), dim3(64), 0, s, a);
+  }
   static const Ops* get() {
     static const Ops ops = {
         LayoutInfo{C::N, C::K, G, C::TPW, C::LPT, C::RW, C::TILE_BYTES, C::TILE_PAYLOAD},
-        C::WPB, &step, &init, &get_state, &set_state, &move_record, &outputs, &pack_meas};
+        C::WPB, &step, &init, &get_state, &set_state, &move_record, &outputs, &pack_meas, &intersect};
     return &ops;
   }
 };

@@ -407,6 +407,61 @@ long TargetManager::getStateBatch(const unsigned* ids, long n, double* x, double
   return batches_[(size_t)b0]->n_state();
 }
 
+double TargetManager::getIntersectionTimeWithSphere(unsigned id, double t1, const double* origin, double radius) {
+  lock_guard<mutex> lg(target_lock_);
+  Loc loc;
+  if (!find(id, loc)) return -1;
+  double d = -1;
+  batches_[(size_t)loc.batch]->intersect(&loc.slot, 1, t1, origin, radius, &d, nullptr);
+  return d;
+}
+
+bool TargetManager::getIntersectionPoseWithSphere(unsigned id, double t1, const double* origin, double radius,
+                                                  double* pose7, double* delta) {
+  lock_guard<mutex> lg(target_lock_);
+  pose7[0] = pose7[1] = pose7[2] = pose7[3] = pose7[4] = pose7[5] = 0.0;
+  pose7[6] = 1.0;  // initPose, intersection_solver.cpp:99
+  if (delta) *delta = -1;
+  Loc loc;
+  if (!find(id, loc)) return false;
+  double d = -1;
+  batches_[(size_t)loc.batch]->intersect(&loc.slot, 1, t1, origin, radius, &d, pose7);
+  if (delta) *delta = d;
+  return d > -1;
+}
+
+long TargetManager::intersectBatch(const unsigned* ids, long n, double t1, const double* origin, double radius,
+                                   double* delta, double* pose, unsigned char* found) {
+  lock_guard<mutex> lg(target_lock_);
+  const size_t nb = batches_.size();
+  std::vector<std::vector<int>> slots(nb);
+  std::vector<std::vector<long>> src(nb);
+  long done = 0;
+  for (long i = 0; i < n; ++i) {
+    Loc loc;
+    const bool ok = find(ids[i], loc);
+    if (found) found[i] = ok ? 1 : 0;
+    delta[i] = -1;
+    if (pose) { for (int c = 0; c < 6; ++c) pose[i * 7 + c] = 0.0; pose[i * 7 + 6] = 1.0; }
+    if (!ok) continue;
+    slots[(size_t)loc.batch].push_back(loc.slot);
+    src[(size_t)loc.batch].push_back(i);
+    ++done;
+  }
+  for (size_t b = 0; b < nb; ++b) {
+    const long k = (long)slots[b].size();
+    if (!k) continue;
+    std::vector<double> d2((size_t)k), p2(pose ? (size_t)k * 7 : 0);
+    batches_[b]->intersect(slots[b].data(), k, t1, origin, radius, d2.data(), pose ? p2.data() : nullptr);
+    for (long j = 0; j < k; ++j) {
+      const long i = src[b][(size_t)j];
+      delta[i] = d2[(size_t)j];
+      if (pose) std::memcpy(pose + i * 7, &p2[(size_t)j * 7], sizeof(double) * 7);
+    }
+  }
+  return done;
+}
+
 Batch* TargetManager::batchOfType(int type) {
   for (auto& b : batches_)
     if (b->type() == type) return b.get();

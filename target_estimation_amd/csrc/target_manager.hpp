@@ -75,6 +75,15 @@ class TargetManager {
   long getPoseBatch(const unsigned* ids, long n, double* pose, double* twist, double* acc, unsigned char* found,
                     bool at_time = false, double t1 = 0.0);
   long getStateBatch(const unsigned* ids, long n, double* x, double* P);
+  // IntersectionSolver::getIntersectionTimeWithSphere (src/intersection_solver.cpp:42-89): time from
+  // t1 to the first crossing of the sphere, -1 if none or unknown id.
+  double getIntersectionTimeWithSphere(unsigned id, double t1, const double* origin, double radius);
+  // IntersectionSolver::getIntersectionPoseWithSphere without its moving-average convergence gate
+  // (src/intersection_solver.cpp:91-104): true if an intersection exists; pose7 = pose at t1+delta.
+  bool getIntersectionPoseWithSphere(unsigned id, double t1, const double* origin, double radius, double* pose7,
+                                     double* delta = nullptr);
+  long intersectBatch(const unsigned* ids, long n, double t1, const double* origin, double radius, double* delta,
+                      double* pose, unsigned char* found);
 
   int numBatches() const { return (int)batches_.size(); }
   Batch* batch(int i) { return batches_[(size_t)i].get(); }

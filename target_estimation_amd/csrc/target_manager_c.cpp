@@ -195,6 +195,40 @@ int target_manager_get_time(target_manager_c* self, unsigned int id, double* t) 
   return r;
 }
 
+double target_manager_get_intersection_time_with_sphere(target_manager_c* self, unsigned int id, double t1,
+                                                         const double* origin, double radius) {
+  double d = -1;
+  guarded("target_manager_get_intersection_time_with_sphere", [&] {
+    d = M(self)->getIntersectionTimeWithSphere(id, t1, origin, radius);
+  });
+  return d;
+}
+
+bool target_manager_get_intersection_pose_with_sphere(target_manager_c* self, unsigned int id, double t1,
+                                                      const double* origin, double radius, double* pose,
+                                                      double* delta) {
+  bool r = false;
+  guarded("target_manager_get_intersection_pose_with_sphere", [&] {
+    r = M(self)->getIntersectionPoseWithSphere(id, t1, origin, radius, pose, delta);
+  });
+  return r;
+}
+
+long target_manager_intersect_sphere_batch(target_manager_c* self, const unsigned int* ids, long n, double t1,
+                                           const double* origin, double radius, double* delta, double* pose,
+                                           unsigned char* found) {
+  long k = -1;
+  guarded("target_manager_intersect_sphere_batch", [&] {
+    k = M(self)->intersectBatch(ids, n, t1, origin, radius, delta, pose, found);
+  });
+  return k;
+}
+
+int target_batch_intersect_sphere_dev(target_batch_c* b, double t1, const double* origin, double radius,
+                                      double* delta_dev, double* pose_dev) {
+  return guarded("target_batch_intersect_sphere_dev", [&] { B(b)->intersect_dev(t1, origin, radius, delta_dev, pose_dev); });
+}
+
 int target_manager_num_batches(target_manager_c* self) { return M(self)->numBatches(); }
 
 target_batch_c* target_manager_get_batch(target_manager_c* self, int index) {

@@ -88,6 +88,19 @@ class Batch:
                                                    0.0 if t1 is None else float(t1)), "target_batch_get_est_dev")
         return p, t, a
 
+    def intersect_sphere(self, origin, radius, t1=None, want_pose=True):
+        """Sphere-intersection query for every slot: (delta [size], pose [size,7] or None) as CUDA double
+        tensors; t1=None queries each target at its own current time."""
+        import torch
+        n = self.size
+        delta = torch.empty(n, dtype=torch.float64, device="cuda")
+        pose = torch.empty((n, 7), dtype=torch.float64, device="cuda") if want_pose else None
+        origin = _d(origin, (3,))
+        _check(self._lib.target_batch_intersect_sphere_dev(
+            self._h, float("nan") if t1 is None else float(t1), _dp(origin), float(radius), delta.data_ptr(),
+            None if pose is None else pose.data_ptr()), "target_batch_intersect_sphere_dev")
+        return delta, pose
+
     def pack_meas(self, meas_aos, out=None):
         """CUDA double [n,7] (the reference's row layout) -> SoA [7,n] in the batch precision."""
         import torch
@@ -237,6 +250,28 @@ class TargetManager:
                     "target_manager_get_state_batch")
         return (x.reshape(-1)[:n * ns].reshape(n, ns).copy(),
                 P.reshape(-1)[:n * ns * ns].reshape(n, ns, ns).copy())
+
+    def intersection_time(self, id, t1, origin, radius):
+        origin = _d(origin, (3,))
+        return self._lib.target_manager_get_intersection_time_with_sphere(self._h, int(id), float(t1), _dp(origin), float(radius))
+
+    def intersection_pose(self, id, t1, origin, radius):
+        origin = _d(origin, (3,))
+        pose = np.zeros(7)
+        d = C.c_double()
+        ok = self._lib.target_manager_get_intersection_pose_with_sphere(self._h, int(id), float(t1), _dp(origin), float(radius),
+                                                                         _dp(pose), C.byref(d))
+        return bool(ok), pose, d.value
+
+    def intersect_batch(self, ids, t1, origin, radius):
+        ids, idp = _ids(ids)
+        n = len(ids)
+        origin = _d(origin, (3,))
+        delta = np.empty(n); pose = np.empty((n, 7)); found = np.zeros(n, dtype=np.uint8)
+        _check(self._lib.target_manager_intersect_sphere_batch(self._h, idp, n, float(t1), _dp(origin), float(radius),
+                                                               _dp(delta), _dp(pose), found.ctypes.data_as(capi.c_ubyte_p)),
+               "target_manager_intersect_sphere_batch")
+        return delta, pose, found.astype(bool)
 
     def batches(self):
         return [Batch(self._lib, self._lib.target_manager_get_batch(self._h, i))

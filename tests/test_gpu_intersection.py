@@ -1,0 +1,85 @@
+"""Sphere-intersection query (IntersectionSolver, src/intersection_solver.cpp:42-104) on the GPU vs
+the oracle.  Parity here is unpinned by the reference (it has no test for the solver, and its root
+finder is Eigen's companion-matrix eigen-solver): the oracle's long-double Aberth roots are checked
+against numpy.roots in tests/test_oracle_kat.py."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import model_path
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+te = pytest.importorskip("target_estimation_amd")
+
+
+def scene(N, seed):
+    rng = np.random.default_rng(seed)
+    d = rng.normal(size=(N, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    r = rng.uniform(0.5, 12.0, N)               # some targets start inside the sphere (radius 5)
+    p = d * r[:, None]
+    v = -d * rng.uniform(1.0, 6.0, N)[:, None] + rng.normal(0, 0.8, (N, 3))   # roughly inbound
+    a = rng.normal(0, 1.0, (N, 3)) + np.array([0, 0, -2.0])
+    p0 = np.concatenate([p, np.tile([0, 0, 0, 1.0], (N, 1))], 1)
+    v0 = np.concatenate([v, rng.normal(0, 0.2, (N, 3))], 1)
+    a0 = np.concatenate([a, rng.normal(0, 0.05, (N, 3))], 1)
+    return p0, v0, a0
+
+
+@pytest.mark.parametrize("name,dtype", [("uniform_acceleration", "f64"), ("angular_rates", "f64"),
+                                         ("uniform_acceleration", "f32"), ("angular_rates", "f32"),
+                                         ("uniform_velocity", "f64"), ("angular_velocities", "f64")])
+def test_intersection_matches_oracle(models, name, dtype):
+    m = models[name]
+    N, dt = 400, 0.004
+    p0, v0, a0 = scene(N, 9)
+    ids = np.arange(N, dtype=np.uint32)
+    mgr = te.TargetManager(model_path(name), dtype=dtype)
+    mgr.init_batch(ids, dt, 0.0, p0, v0, a0)
+    orc = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], p0, dt, 0.0, v0, a0, dtype=dtype)
+    rng = np.random.default_rng(1)
+    for s in range(3):                            # a few ticks so the query runs on filtered state
+        meas = p0.copy()
+        t = (s + 1) * dt
+        meas[:, :3] = p0[:, :3] + v0[:, :3] * t + 0.5 * a0[:, :3] * t * t + rng.normal(0, 0.01, (N, 3))
+        mgr.update_batch(ids, dt, meas)
+        orc.step(dt, meas)
+    origin, radius, t1 = np.array([0.1, -0.2, 0.3]), 5.0, 3 * dt + 0.05
+    ok_o, pose_o, delta_o = orc.intersection_pose(t1, origin, radius)
+    delta, pose, found = mgr.intersect_batch(ids, t1, origin, radius)
+    assert found.all()
+    if name in ("uniform_velocity", "angular_velocities"):
+        # zero acceleration => leading coefficient 0 => "no intersection" (intersection_solver.cpp:6-9)
+        assert (delta == -1).all() and (delta_o == -1).all()
+        np.testing.assert_array_equal(pose, np.tile([0, 0, 0, 0, 0, 0, 1.0], (N, 1)))
+        mgr.close()
+        return
+    hit_o, hit = delta_o > -1, delta > -1
+    assert hit_o.sum() > 50 and (~hit_o).sum() > 50          # the scene exercises both outcomes
+    # classification may differ only where a root sits at the |imag| threshold or at delta = 0
+    assert (hit != hit_o).mean() <= (0.0 if dtype == "f64" else 0.01)
+    both = hit & hit_o
+    rtol = 1e-9 if dtype == "f64" else 2e-4
+    np.testing.assert_allclose(delta[both], delta_o[both], rtol=rtol, atol=rtol)
+    np.testing.assert_allclose(pose[both], pose_o[both], atol=1e-8 if dtype == "f64" else 5e-3)
+    # the returned time is a crossing of the sphere
+    d = np.linalg.norm(pose[both][:, :3] - origin, axis=1)
+    np.testing.assert_allclose(d, radius, atol=1e-7 if dtype == "f64" else 5e-3)
+    # scalar entry points agree with the batch, unknown id -> -1 / false
+    for i in (0, 1, 2, int(np.argmax(hit))):
+        assert mgr.intersection_time(i, t1, origin, radius) == delta[i]
+        ok, p7, d1 = mgr.intersection_pose(i, t1, origin, radius)
+        assert ok == bool(hit[i]) and d1 == delta[i]
+        np.testing.assert_array_equal(p7, pose[i])
+    assert mgr.intersection_time(10 ** 6, t1, origin, radius) == -1
+    # dense device query at each target's own time (configs[4] per-tick form)
+    b = mgr.batches()[0]
+    dd, pp = b.intersect_sphere(origin, radius)
+    ok2, pose2, delta2 = orc.intersection_pose(3 * dt, origin, radius)
+    dd = dd.cpu().numpy()
+    same = (dd > -1) == (delta2 > -1)
+    assert same.mean() >= (1.0 if dtype == "f64" else 0.99)
+    sel = (dd > -1) & (delta2 > -1)
+    np.testing.assert_allclose(dd[sel], delta2[sel], rtol=rtol, atol=rtol)
+    mgr.close()
