@@ -22,6 +22,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
+# lanes-per-target tuned on MI355X (tools/sweep.py): small, latency-bound batches want more lanes per
+# target, large HBM-bound ones fewer.  0 = the library default.
+TUNED_LANES = {"cfg2": 3, "cfg3": 1, "cfg4ar": 6, "cfg4av": 3, "uv1m": 1, "ua1m": 1, "ar1m": 6, "av1m": 3,
+               "ar1m64": 3, "av1m64": 6}
+
 WORKLOADS = {
     # name: (description, model, dtype, targets per GPU, seed)
     "cfg2": ("10000 targets, uniform-velocity model, fp64 (BASELINE.json configs[1])", "uniform_velocity", "f64", 10_000, 20240002),
@@ -37,11 +42,14 @@ WORKLOADS = {
 }
 
 
-def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None, rank=0, world=1, stream_ticks=32):
+def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None, rank=0, world=1, stream_ticks=32,
+                 launch_mode="graph"):
     from target_estimation_amd.streams import make_stream
     desc, model, dtype, n_targets, seed = WORKLOADS[name]
     if targets:
         n_targets = targets
+    if not lanes:
+        lanes = TUNED_LANES.get(name, 0)
     path = os.path.join(ROOT, "models", "model_%s_params.yaml" % model)
     mgr = te.TargetManager(path, dtype=dtype, lanes_per_target=lanes)
     mgr.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -56,11 +64,29 @@ def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None,
     meas = st["meas"].to(b.torch_dtype()).contiguous()   # [ticks, 7, N] in the batch precision
     torch.cuda.synchronize()
 
-    def tick(s):
-        b.step(dt, meas[s % ticks])
+    # One launch of the step kernel per tick in every mode.  "python": one C-ABI call per tick;
+    # "sequence": the launches of a block of ticks are enqueued by one C call
+    # (target_batch_step_sequence); "graph": that block is a recorded hipGraph that is replayed.
+    done = [0]
 
-    for s in range(warmup):
-        tick(s)
+    def run_ticks(count):
+        if launch_mode == "python":
+            for _ in range(count):
+                b.step(dt, meas[done[0] % ticks])
+                done[0] += 1
+            return
+        while count > 0:
+            off = done[0] % ticks
+            blk = min(count, ticks - off)
+            # only whole blocks are replayed from the recorded graph (one graph, recorded during
+            # warm-up); partial blocks are enqueued launch by launch
+            b.step_sequence(dt, meas[off:off + blk], use_graph=(launch_mode == "graph" and off == 0 and blk == ticks))
+            done[0] += blk
+            count -= blk
+
+    if launch_mode == "graph":
+        b.step_sequence(dt, meas, use_graph=2)   # record the block's graph now (set-up; launches nothing)
+    run_ticks(warmup)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -68,8 +94,7 @@ def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None,
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for s in range(steps):
-        tick(warmup + s)
+    run_ticks(steps)
     ev1.record()
     torch.cuda.synchronize()
     if dist is not None:
@@ -78,7 +103,7 @@ def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None,
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     dev_ms = ev0.elapsed_time(ev1)
@@ -94,7 +119,7 @@ def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None,
         device_ms_per_launch=launch_s * 1e3,
         algorithmic_bytes_per_cycle=b.algorithmic_bytes, algorithmic_bytes_per_launch=alg_bytes,
         achieved_gbs=alg_bytes / launch_s / 1e9,
-        resident_bytes_per_target=b.resident_bytes_per_target)
+        resident_bytes_per_target=b.resident_bytes_per_target, launch_mode=launch_mode)
     res["_mgr"] = (mgr, b, st, ids, dt)
     return res
 
@@ -160,22 +185,25 @@ def main():
     ap.add_argument("--extra", default="uv1m,ar1m,av1m,ua1m", help="comma list of extra workloads reported under 'extra' (N=1 only; '' = none)")
     ap.add_argument("--extra-steps", type=int, default=50)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--launch-mode", default="graph", choices=["python", "sequence", "graph"],
+                    help="how the per-tick launches are enqueued (always one kernel launch per tick)")
     args = ap.parse_args()
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
-        dist_mod.init_process_group("nccl")
+        # "nccl" is RCCL on ROCm.  TE_BENCH_BACKEND=gloo rehearses the multi-rank path on a one-GPU box.
+        dist_mod.init_process_group(os.environ.get("TE_BENCH_BACKEND", "nccl"))
         dist = dist_mod
     import target_estimation_amd as te
 
     res = run_workload(te, torch, args.workload, args.steps, args.warmup, args.lanes, args.targets or None,
-                       dist, rank, world)
+                       dist, rank, world, launch_mode=args.launch_mode)
     mgr = res.pop("_mgr")
     out = {
         "metric": "KF predict+update cycles/sec over N targets",
@@ -185,7 +213,7 @@ def main():
         "vs_baseline": None, "dtype": res["dtype"], "data": "synthetic",
         "config": {"workload": res["desc"], "name": res["name"], "model": res["model"],
                    "targets_per_gpu": res["targets_per_gpu"], "targets_total": res["targets_per_gpu"] * world,
-                   "lanes_per_target": res["lanes_per_target"], "dt": 0.004,
+                   "lanes_per_target": res["lanes_per_target"], "dt": 0.004, "launch_mode": res["launch_mode"],
                    "sharding": "contiguous id ranges per rank, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": res["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": res["achieved_gbs"] / HBM_PEAK_GBS, "traffic": None,
@@ -202,7 +230,7 @@ def main():
         for name in [e for e in args.extra.split(",") if e]:
             if name == args.workload:
                 continue
-            r = run_workload(te, torch, name, args.extra_steps, 10, 0)
+            r = run_workload(te, torch, name, args.extra_steps, 10, 0, launch_mode=args.launch_mode)
             r.pop("_mgr")
             extras.append({k: r[k] for k in ("name", "desc", "dtype", "targets_per_gpu", "lanes_per_target", "cycles_per_s",
                                             "ms_per_step", "device_ms_per_launch", "achieved_gbs",

@@ -118,6 +118,13 @@ long target_batch_slot_ids(target_batch_c* b, unsigned int* ids_out, long capaci
  *                 for all slots), or NULL for predict-only.  Linear models read rows 0..2 only.
  *   has_meas_dev: per-slot bytes, or NULL (every slot has a measurement). */
 int target_batch_step(target_batch_c* b, double dt, const void* meas_dev, long ld, const unsigned char* has_meas_dev);
+/* n_ticks consecutive ticks = n_ticks launches of the step kernel, enqueued in one call: tick s
+ * reads meas_dev + s * tick_stride elements (and has_meas_dev + s * has_stride bytes).  With
+ * use_graph != 0 the launches are recorded once into a hipGraph (keyed by the arguments) and
+ * replayed: for replaying recorded streams at small batch sizes, where the tick is launch-bound.
+ * use_graph == 2 records the graph and launches nothing (set-up before a timed region). */
+int target_batch_step_sequence(target_batch_c* b, long n_ticks, double dt, const void* meas_dev, long tick_stride, long ld,
+                               const unsigned char* has_meas_dev, long has_stride, int use_graph);
 /* derived outputs of every slot into device arrays of doubles ([size][7], [size][6], [size][6];
  * any may be NULL); at_time != 0 extrapolates to t1 */
 int target_batch_get_est_dev(target_batch_c* b, double* pose_dev, double* twist_dev, double* acc_dev, int at_time, double t1);

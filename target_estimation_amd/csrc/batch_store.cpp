@@ -40,6 +40,8 @@ Batch::Batch(int type, int dtype, int lanes, const double* Q, const double* R, h
 
 Batch::~Batch() {
   (void)hipStreamSynchronize(stream_);
+  drop_graphs();
+  if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
   (void)hipFree(d_qr_); (void)hipFree(d_rec_); (void)hipFree(d_tbase_); (void)hipFree(d_nmbase_);
   (void)hipFree(d_idx_); (void)hipFree(d_aos_); (void)hipFree(d_meas_); (void)hipFree(d_mask_); (void)hipFree(d_P0_);
   (void)hipHostFree(h_ring_idx_); (void)hipHostFree(h_ring_meas_); (void)hipHostFree(h_ring_out_);
@@ -82,6 +84,7 @@ void Batch::reserve(long n) {
   TE_HIP_CHECK(hipStreamSynchronize(stream_));
   (void)hipFree(d_rec_); (void)hipFree(d_tbase_); (void)hipFree(d_nmbase_);
   d_rec_ = rec; d_tbase_ = tb; d_nmbase_ = nm; cap_ = want;
+  drop_graphs();
 }
 
 void Batch::stage_reserve(long n) {
@@ -159,6 +162,50 @@ void Batch::step_dense(double dt, const void* meas_dev, long ld, const unsigned 
   ops_->step(p, stream_);
   t_acc_ += dt;
   if (meas_dev && !has_dev) nm_acc_ += 1;
+}
+
+void Batch::drop_graphs() {
+  for (auto& g : graphs_) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+  graphs_.clear();
+}
+
+void Batch::step_sequence(long n_ticks, double dt, const void* meas_base, long tick_stride, long ld,
+                          const unsigned char* has_base, long has_stride, int use_graph) {
+  if (n_ == 0 || n_ticks <= 0) return;
+  const size_t es = elem_size();
+  auto params = [&](long s) {
+    StepParams p;
+    p.rec = d_rec_; p.qr = d_qr_; p.n = n_; p.idx = nullptr;
+    p.meas = meas_base ? static_cast<const char*>(meas_base) + (size_t)(s * tick_stride) * es : nullptr;
+    p.meas_ld = ld;
+    p.has_meas = has_base ? has_base + s * has_stride : nullptr;
+    p.dt_per = nullptr; p.dt = dt; p.t_base = d_tbase_; p.nm_base = d_nmbase_;
+    return p;
+  };
+  if (!use_graph) {
+    for (long s = 0; s < n_ticks; ++s) ops_->step(params(s), stream_);
+    TE_HIP_CHECK(hipGetLastError());
+  } else {
+    GraphEntry* hit = nullptr;
+    for (auto& g : graphs_)
+      if (g.n_ticks == n_ticks && g.tick_stride == tick_stride && g.ld == ld && g.has_stride == has_stride && g.n == n_ &&
+          g.dt == dt && g.meas_base == meas_base && g.has_base == has_base && g.rec == d_rec_) hit = &g;
+    if (!hit) {
+      if (graphs_.size() >= 8) drop_graphs();
+      if (!cap_stream_) TE_HIP_CHECK(hipStreamCreateWithFlags(&cap_stream_, hipStreamNonBlocking));
+      GraphEntry e{n_ticks, tick_stride, ld, has_stride, n_, dt, meas_base, has_base, d_rec_, nullptr, nullptr};
+      TE_HIP_CHECK(hipStreamBeginCapture(cap_stream_, hipStreamCaptureModeThreadLocal));
+      for (long s = 0; s < n_ticks; ++s) ops_->step(params(s), cap_stream_);
+      TE_HIP_CHECK(hipStreamEndCapture(cap_stream_, &e.graph));
+      TE_HIP_CHECK(hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
+      graphs_.push_back(e);
+      hit = &graphs_.back();
+    }
+    if (use_graph == 2) return;  // record only
+    TE_HIP_CHECK(hipGraphLaunch(hit->exec, stream_));
+  }
+  t_acc_ += dt * (double)n_ticks;
+  if (meas_base && !has_base) nm_acc_ += n_ticks;
 }
 
 void Batch::step_indexed(const int* slots, long n, double dt, const double* meas_aos, const unsigned char* has) {

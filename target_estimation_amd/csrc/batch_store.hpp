@@ -45,6 +45,12 @@ class Batch {
   //   meas_dev: SoA [7][ld] in the batch precision, or null (predict only = TargetInterface::update)
   //   has_dev : per-slot mask or null (all have a measurement)
   void step_dense(double dt, const void* meas_dev, long ld, const unsigned char* has_dev);
+  // n_ticks consecutive dense ticks, tick s reading meas_base + s * tick_stride (elements of the
+  // batch precision) and has_base + s * has_stride: exactly n_ticks launches of the step kernel,
+  // enqueued from C++ (use_graph 1: recorded once into a hipGraph and replayed, which removes the
+  // per-launch host cost when a recorded stream is replayed; 2: record only, launch nothing).
+  void step_sequence(long n_ticks, double dt, const void* meas_base, long tick_stride, long ld,
+                     const unsigned char* has_base, long has_stride, int use_graph);
   // One tick over the listed slots, host inputs (meas rows follow the order of `slots`).
   void step_indexed(const int* slots, long n, double dt, const double* meas_aos, const unsigned char* has);
   void step_one(long slot, double dt, const double* meas7);
@@ -100,6 +106,18 @@ class Batch {
   unsigned char* d_mask_ = nullptr;
   double* d_P0_ = nullptr;
   long P0_cap_ = 0;
+  struct GraphEntry {
+    long n_ticks, tick_stride, ld, has_stride, n;
+    double dt;
+    const void* meas_base;
+    const unsigned char* has_base;
+    char* rec;
+    hipGraphExec_t exec;
+    hipGraph_t graph;
+  };
+  std::vector<GraphEntry> graphs_;
+  hipStream_t cap_stream_ = nullptr;
+  void drop_graphs();
   // pinned, device-visible ring for the one-target calls of the reference's C ABI
   static constexpr int kRing = 1024;
   int ring_head_ = 0;

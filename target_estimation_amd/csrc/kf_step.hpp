@@ -97,18 +97,15 @@ __global__ void __launch_bounds__((Cfg<M, T, G>::WPB * 64)) kf_step_kernel(const
   constexpr int kStepWaves = C::WPB, kStepThreads = C::WPB * 64;
   using F = Mth<T>;
 
-  __shared__ T s_qr[N * N + K * K];
+  // Q and R are staged per wavefront (no workgroup barrier anywhere in the kernel), after the
+  // record loads have been issued so that both round trips overlap.
+  __shared__ T s_qr[C::QR_WORDS * kStepWaves];
   __shared__ T s_ex[(C::EX_WORDS > 0 ? C::EX_WORDS : 1) * kStepWaves];
-
-  for (int e = threadIdx.x; e < N * N + K * K; e += kStepThreads) s_qr[e] = a.qr[e];
-  __syncthreads();
-  const T* sQ = s_qr;
-  const T* sR = s_qr + N * N;
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const long wg = (long)blockIdx.x * kStepWaves + wave;  // wavefront-global index
-  if (wg * TPW >= a.n) return;                           // wave-uniform; no block barrier follows
+  if (wg * TPW >= a.n) return;                           // wave-uniform
   const int g = lane / G;
   const int i = (G == 1) ? 0 : lane % G;
   const long entry = wg * TPW + g;
@@ -133,6 +130,11 @@ __global__ void __launch_bounds__((Cfg<M, T, G>::WPB * 64)) kf_step_kernel(const
 #pragma unroll
     for (int w = 0; w < C::RW; ++w) rec[w] = 0;
   }
+  T* sQw = s_qr + C::QR_WORDS * wave;
+  for (int e = lane; e < C::QR_WORDS; e += 64) sQw[e] = a.qr[e];
+  wave_lds_fence();
+  const T* sQ = sQw;
+  const T* sR = sQw + N * N;
   // views into the record (compile-time indices only)
 #define P_(q, c) rec[(q) * N + (c)]
 #define X_(q) rec[C::X_OFF + (q)]
@@ -315,22 +317,55 @@ __global__ void __launch_bounds__((Cfg<M, T, G>::WPB * 64)) kf_step_kernel(const
 
   // ------------------------------------------------------------------ update (estimate)
   if (has) {
-    // S = P^-[0:K,0:K] + R, rows owned by this lane; unpivoted in-place Gauss-Jordan
-    T S[KPL][K];
-#pragma unroll
-    for (int qq = 0; qq < KPL; ++qq)
-#pragma unroll
-      for (int c = 0; c < K; ++c) S[qq][c] = P_(qq, c) + sR[(i + G * qq) * K + c];
-#pragma unroll
-    for (int p = 0; p < K; ++p) {
-      const int ip = p % G, qp = p / G;
-      T prow[K];
+    // S = P^-[0:K,0:K] + R and its inverse by unpivoted in-place Gauss-Jordan (S is SPD).
+    //  LOCAL_INV (G == 1, or K == 3): every lane holds all of S and inverts it privately (one LDS
+    //    round trip to collect the rows when G > 1; 27 fma for K = 3);
+    //  otherwise (K == 6, G > 1): rows stay distributed, the scaled pivot row of each of the K
+    //    elimination steps goes through LDS, and S^-1 is published for the gain.
+    // Both orders of operations are the same, so every G gives bit-identical results.
+    constexpr bool LOCAL_INV = (G == 1) || (K == 3);
+    T S[LOCAL_INV ? K : KPL][K];
+    if constexpr (LOCAL_INV) {
       if constexpr (G == 1) {
-        const T inv = (T)1 / S[qp][p];
-        S[qp][p] = 1;
 #pragma unroll
-        for (int c = 0; c < K; ++c) { S[qp][c] *= inv; prow[c] = S[qp][c]; }
+        for (int r = 0; r < K; ++r)
+#pragma unroll
+          for (int c = 0; c < K; ++c) S[r][c] = P_(r, c) + sR[r * K + c];
       } else {
+#pragma unroll
+        for (int qq = 0; qq < KPL; ++qq)
+#pragma unroll
+          for (int c = 0; c < K; ++c) EXB_((i + G * qq) * K + c) = P_(qq, c) + sR[(i + G * qq) * K + c];
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < K; ++r)
+#pragma unroll
+          for (int c = 0; c < K; ++c) S[r][c] = EXB_(r * K + c);
+      }
+#pragma unroll
+      for (int p = 0; p < K; ++p) {
+        const T inv = (T)1 / S[p][p];
+        S[p][p] = 1;
+#pragma unroll
+        for (int c = 0; c < K; ++c) S[p][c] *= inv;
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+          if (r == p) continue;
+          const T f = S[r][p];
+          S[r][p] = 0;
+#pragma unroll
+          for (int c = 0; c < K; ++c) S[r][c] = F::fma(-f, S[p][c], S[r][c]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int qq = 0; qq < KPL; ++qq)
+#pragma unroll
+        for (int c = 0; c < K; ++c) S[qq][c] = P_(qq, c) + sR[(i + G * qq) * K + c];
+#pragma unroll
+      for (int p = 0; p < K; ++p) {
+        const int ip = p % G, qp = p / G;
+        T prow[K];
         if (i == ip) {
           const T inv = (T)1 / S[qp][p];
           S[qp][p] = 1;
@@ -341,25 +376,26 @@ __global__ void __launch_bounds__((Cfg<M, T, G>::WPB * 64)) kf_step_kernel(const
 #pragma unroll
         for (int c = 0; c < K; ++c) prow[c] = EXC_(c);
         wave_lds_fence();
+#pragma unroll
+        for (int qq = 0; qq < KPL; ++qq) {
+          const bool is_piv = (qq == qp) && (i == ip);
+          const T f = is_piv ? (T)0 : S[qq][p];
+          if (!is_piv) S[qq][p] = 0;
+#pragma unroll
+          for (int c = 0; c < K; ++c) S[qq][c] = F::fma(-f, prow[c], S[qq][c]);
+        }
       }
 #pragma unroll
-      for (int qq = 0; qq < KPL; ++qq) {
-        const bool is_piv = (qq == qp) && (i == ip);
-        const T f = is_piv ? (T)0 : S[qq][p];
-        if (!is_piv) S[qq][p] = 0;
-#pragma unroll
-        for (int c = 0; c < K; ++c) S[qq][c] = F::fma(-f, prow[c], S[qq][c]);
-      }
-    }
-    // publish S^-1 and the top K rows of P^- (both needed by every lane of the group)
-    if constexpr (G > 1) {
-#pragma unroll
-      for (int qq = 0; qq < KPL; ++qq) {
+      for (int qq = 0; qq < KPL; ++qq)
 #pragma unroll
         for (int c = 0; c < K; ++c) EXB_((i + G * qq) * K + c) = S[qq][c];
+    }
+    // publish the top K rows of P^- (needed by every lane of the group for the covariance update)
+    if constexpr (G > 1) {
+#pragma unroll
+      for (int qq = 0; qq < KPL; ++qq)
 #pragma unroll
         for (int c = 0; c < N; ++c) EXA_((i + G * qq) * N + c) = P_(qq, c);
-      }
     }
     // innovation y - x^-[0:K]; y = xyz | unwrapped rpy (angular_rates.cpp:81-88)
     T nu[K];
@@ -401,7 +437,7 @@ __global__ void __launch_bounds__((Cfg<M, T, G>::WPB * 64)) kf_step_kernel(const
 #pragma unroll
       for (int c = 0; c < K; ++c) {
         T v;
-        if constexpr (G == 1) v = S[c][l]; else v = EXB_(c * K + l);
+        if constexpr (LOCAL_INV) v = S[c][l]; else v = EXB_(c * K + l);
 #pragma unroll
         for (int q = 0; q < RPL; ++q) Kg[q][l] = (c == 0) ? P_(q, 0) * v : F::fma(P_(q, c), v, Kg[q][l]);
       }

@@ -65,8 +65,8 @@ struct Cfg {
   static constexpr int EX_WORDS = (G == 1) ? 0 : GS * (EXA + EXB + EXC);
   static constexpr int QR_WORDS = N * N + K * K;
   // wavefronts per workgroup: as many as keep static LDS under 64 KiB
-  static constexpr long LDS4 = (long)(QR_WORDS + 4 * EX_WORDS) * (long)sizeof(T);
-  static constexpr long LDS2 = (long)(QR_WORDS + 2 * EX_WORDS) * (long)sizeof(T);
+  static constexpr long LDS4 = (long)(4 * (QR_WORDS + EX_WORDS) + 1) * (long)sizeof(T);
+  static constexpr long LDS2 = (long)(2 * (QR_WORDS + EX_WORDS) + 1) * (long)sizeof(T);
   static constexpr int WPB = (LDS4 <= 65536) ? 4 : ((LDS2 <= 65536) ? 2 : 1);
 };
 

@@ -68,7 +68,7 @@ class Batch:
         (predict only); has_meas: CUDA uint8 tensor [size] or None.  Asynchronous."""
         mp, ld, hp = None, 0, None
         if meas is not None:
-            assert meas.is_cuda and meas.dim() == 2 and meas.shape[0] == 7 and meas.stride(1) == 1
+            assert meas.is_cuda and meas.dim() == 2 and meas.shape[0] == 7 and (meas.shape[1] == 1 or meas.stride(1) == 1)
             assert meas.dtype == self.torch_dtype(), (meas.dtype, self.dtype)
             assert meas.shape[1] >= self.size
             mp, ld = meas.data_ptr(), meas.stride(0)
@@ -76,6 +76,18 @@ class Batch:
             assert has_meas.is_cuda and has_meas.numel() >= self.size and has_meas.element_size() == 1
             hp = has_meas.data_ptr()
         _check(self._lib.target_batch_step(self._h, float(dt), mp, ld, hp), "target_batch_step")
+
+    def step_sequence(self, dt, meas, has_meas=None, use_graph=False):
+        """meas: CUDA tensor [ticks, 7, ld]: one launch per tick, all enqueued by one C call."""
+        assert meas.is_cuda and meas.dim() == 3 and meas.shape[1] == 7 and (meas.shape[2] == 1 or meas.stride(2) == 1)
+        assert meas.dtype == self.torch_dtype() and meas.shape[2] >= self.size
+        hp, hs = None, 0
+        if has_meas is not None:
+            assert has_meas.is_cuda and has_meas.dim() == 2 and has_meas.element_size() == 1
+            hp, hs = has_meas.data_ptr(), has_meas.stride(0)
+        _check(self._lib.target_batch_step_sequence(self._h, meas.shape[0], float(dt), meas.data_ptr(), meas.stride(0),
+                                                     meas.stride(1), hp, hs, int(use_graph)),
+               "target_batch_step_sequence")
 
     def get_est(self, pose=True, twist=True, acc=True, t1=None):
         """Derived outputs of every slot as CUDA double tensors ([size,7], [size,6], [size,6])."""

@@ -1,0 +1,211 @@
+"""Edge cases and full-size properties of the HIP path (MI355X, `pytest -m gpu`)."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import np_twin as tw
+from conftest import HARNESS_ORDER, model_path, synth_stream
+from test_gpu_parity import TOL, check_state, to_soa
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+te = pytest.importorskip("target_estimation_amd")
+
+
+def test_empty_manager_and_empty_calls():
+    mgr = te.TargetManager(model_path("uniform_velocity"))
+    assert mgr.size() == 0 and len(mgr.getAvailableTargets()) == 0 and len(mgr.batches()) == 0
+    mgr.update_all(0.004)                                   # TargetManager::update(dt) on an empty map
+    assert mgr.init_batch(np.zeros(0, np.uint32), 0.004, 0.0, np.zeros((0, 7))) == 0
+    assert mgr.update_batch(np.zeros(0, np.uint32), 0.004, np.zeros((0, 7))) == 0
+    pose, twist, acc, found = mgr.get_est_batch(np.zeros(0, np.uint32))
+    assert pose.shape == (0, 7) and found.shape == (0,)
+    assert mgr.update_batch(np.array([5], np.uint32), 0.004, np.zeros((1, 7))) == 0   # unknown id: skipped
+    mgr.close()
+
+
+@pytest.mark.parametrize("name", ["angular_rates", "angular_velocities"])
+def test_gimbal_branches_of_the_measurement_conversion(models, name):
+    """quatToRpy switches to its alternate solution when |sin pitch| > 0.9999 (geometry.hpp:156-169)."""
+    m = models[name]
+    dt, N = 0.004, 6
+    pitches = [np.pi / 2, -np.pi / 2, np.pi / 2 - 0.005, -np.pi / 2 + 0.005, 1.2, -1.2]
+    q = np.array([tw.rpy_to_quat(np.array([0.3, p, -0.4])) for p in pitches])
+    p0 = np.concatenate([np.zeros((N, 3)), np.tile([0, 0, 0, 1.0], (N, 1))], 1)
+    meas = np.concatenate([np.full((N, 3), 0.01), q], 1)
+    ids = np.arange(N, dtype=np.uint32)
+    mgr = te.TargetManager(model_path(name))
+    mgr.init_batch(ids, dt, 0.0, p0)
+    orc = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], p0, dt)
+    for _ in range(3):
+        mgr.update_batch(ids, dt, meas)
+        orc.step(dt, meas)
+    check_state(mgr, ids, orc, "f64", "gimbal")
+    x, _ = mgr.get_state_batch(ids)
+    assert abs(x[0, 4]) > 0.5 and x[0, 3] != x[4, 3]         # the branch really changed roll
+    mgr.close()
+
+
+@pytest.mark.parametrize("name", HARNESS_ORDER)
+def test_zero_and_large_dt(models, name):
+    m = models[name]
+    N = 40
+    p0, meas = synth_stream(name, N, 4, seed=2)
+    ids = np.arange(N, dtype=np.uint32)
+    mgr = te.TargetManager(model_path(name))
+    mgr.init_batch(ids, 0.004, 0.0, p0)
+    orc = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], p0, 0.004)
+    for s, dt in enumerate([0.0, 1.0, 0.004, 0.25]):
+        mgr.update_batch(ids, dt, meas[s])
+        orc.step(dt, meas[s])
+        check_state(mgr, ids, orc, "f64", "dt=%g" % dt)
+    assert mgr.getTime(3) == pytest.approx(1.254)
+    mgr.close()
+
+
+@pytest.mark.parametrize("name", ["uniform_velocity", "angular_rates"])
+def test_growth_mask_and_per_target_P0(models, name):
+    """Targets appended after the batch has been stepped (reallocation, later t0), an all-zero
+    has_meas mask == predict-only, and per-target P0 through the typed initialiser."""
+    m = models[name]
+    n = m["Q"].shape[0]
+    dt = 0.004
+    rng = np.random.default_rng(4)
+    p0a, measa = synth_stream(name, 10, 8, seed=5)
+    p0b, measb = synth_stream(name, 700, 8, seed=6)
+    P0b = np.stack([m["P"] * rng.uniform(0.5, 2.0) for _ in range(700)])
+    mgr = te.TargetManager(model_path(name))
+    ida, idb = np.arange(10, dtype=np.uint32), np.arange(100, 800, dtype=np.uint32)
+    mgr.init_batch(ida, dt, 0.0, p0a)
+    oa = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], p0a, dt, 0.0)
+    for s in range(4):
+        mgr.update_batch(ida, dt, measa[s])
+        oa.step(dt, measa[s])
+    mgr.init_batch(idb, dt, 4 * dt, p0b, type=m["model"], Q=m["Q"], R=m["R"], P0=P0b)   # same Q,R -> same batch
+    ob = oracle.OracleBatch(m["model"], m["Q"], m["R"], P0b, p0b, dt, 4 * dt)
+    assert len(mgr.batches()) == 1 and mgr.batches()[0].size == 710
+    b = mgr.batches()[0]
+    both = np.concatenate([measa, measb], 1)
+    for s in range(4, 8):
+        if s == 6:
+            b.step(dt, to_soa(both[s], b), torch.zeros(710, dtype=torch.uint8, device="cuda"))
+            oa.step(dt, None); ob.step(dt, None)
+        else:
+            b.step(dt, to_soa(both[s], b))
+            oa.step(dt, measa[s]); ob.step(dt, measb[s])
+    check_state(mgr, ida, oa, "f64", "old targets")
+    check_state(mgr, idb, ob, "f64", "appended targets")
+    assert mgr.getNumberMeasurements(3) == 7 and mgr.getNumberMeasurements(100) == 3
+    assert mgr.getTime(3) == pytest.approx(8 * dt) and mgr.getTime(500) == pytest.approx(8 * dt)
+    _, P = mgr.get_state_batch(idb[:5])
+    assert P.shape == (5, n, n)
+    mgr.close()
+
+
+@pytest.mark.parametrize("name,dtype", [("uniform_velocity", "f64"), ("angular_velocities", "f32")])
+def test_sequence_and_graph_equal_single_steps(models, name, dtype):
+    """target_batch_step_sequence (plain and hipGraph replay) == the same ticks one call at a time."""
+    N, ticks, dt = 500, 16, 0.004
+    p0, meas = synth_stream(name, N, ticks, seed=8)
+    ids = np.arange(N, dtype=np.uint32)
+    out = []
+    for mode in ("single", "sequence", "graph"):
+        mgr = te.TargetManager(model_path(name), dtype=dtype)
+        mgr.init_batch(ids, dt, 0.0, p0)
+        b = mgr.batches()[0]
+        soa = torch.from_numpy(np.ascontiguousarray(meas.transpose(0, 2, 1))).cuda().to(b.torch_dtype()).contiguous()
+        if mode == "single":
+            for s in range(ticks):
+                b.step(dt, soa[s])
+            for s in range(ticks):
+                b.step(dt, soa[s])
+        else:
+            b.step_sequence(dt, soa, use_graph=(mode == "graph"))
+            b.step_sequence(dt, soa, use_graph=(mode == "graph"))      # second call replays the recorded graph
+        out.append(mgr.get_state_batch(ids))
+        assert mgr.getNumberMeasurements(7) == 2 * ticks
+        assert mgr.getTime(7) == pytest.approx(2 * ticks * dt)
+        mgr.close()
+    for x, P in out[1:]:
+        np.testing.assert_array_equal(x, out[0][0])
+        np.testing.assert_array_equal(P, out[0][1])
+
+
+@pytest.mark.parametrize("name", HARNESS_ORDER)
+def test_reference_harness_in_fp32(models, harness_stream, name):
+    """The reference integration test's stream through the fp32 dense path: the reference's own
+    assertions still hold and the state tracks the fp32 oracle."""
+    k = HARNESS_ORDER.index(name)
+    m = models[name]
+    dt = 1.0 / m["frequency"]
+    meas = harness_stream[k]
+    n_points = meas.shape[0]
+    mgr = te.TargetManager(model_path(name), dtype="f32")
+    mgr.init_batch([0], dt, 0.0, meas[:1])
+    b = mgr.batches()[0]
+    orc = oracle.OracleTarget(m["model"], m["Q"], m["R"], m["P"], meas[0], dt, dtype="f32")
+    soa = torch.from_numpy(np.ascontiguousarray(meas[:, :, None].transpose(0, 1, 2))).cuda().float().contiguous()  # [T,7,1]
+    vel_sum = np.zeros(6)
+    block = 500
+    for s0 in range(0, n_points, block):
+        b.step_sequence(dt, soa[s0:s0 + block])
+        for i in range(s0, s0 + block):
+            orc.add_measurement(dt, meas[i])
+        _, twist, _ = b.get_est(pose=False, acc=False)
+        vel_sum += twist[0].cpu().numpy() * block   # coarse mean (block-end samples)
+    pose, twist, _, _ = mgr.get_est_batch([0])
+    goal = np.array([0.2, 0.3, 0.4])
+    np.testing.assert_allclose(pose[0, :3], goal, atol=0.01)
+    np.testing.assert_allclose((vel_sum / n_points)[:3], goal / (n_points * dt), atol=0.01)
+    if name == "angular_velocities":
+        np.testing.assert_allclose(twist[0, 3:], [3.0, 0.01, 0.1], atol=0.01)
+    x, P = mgr.get_state_batch([0])
+    xo, Po = orc.state()
+    # angles reach ~120 rad: one fp32 ulp there is 8e-6, and the filters differ by accumulated rounding
+    np.testing.assert_allclose(x, xo, atol=5e-3, rtol=1e-4)
+    assert np.abs(P - Po).max() <= 5e-2 * np.abs(Po).max()
+    mgr.close()
+
+
+@pytest.mark.parametrize("wl", ["ar1m", "uv1m"])
+def test_full_size_properties(models, wl):
+    """BASELINE-size batches (10^6 targets): properties that do not need the oracle on every target
+    (finite, covariance symmetric to rounding with positive diagonal, slot ids in order, predict-only
+    leaves the covariance PSD-growing), plus a 2000-target random sample against the oracle."""
+    import bench
+    from target_estimation_amd.streams import make_stream
+    desc, name, dtype, N, seed = bench.WORKLOADS[wl]
+    m = models[name]
+    dt, ticks = 0.004, 6
+    st = make_stream(te.MODEL_TYPES[name], N, ticks, dt, seed)
+    ids = np.arange(N, dtype=np.uint32)
+    mgr = te.TargetManager(model_path(name), dtype=dtype, lanes_per_target=bench.TUNED_LANES[wl])
+    p0 = st["p0"].cpu().numpy()
+    assert mgr.init_batch(ids, dt, 0.0, p0) == N
+    b = mgr.batches()[0]
+    assert b.size == N
+    meas = st["meas"].to(b.torch_dtype()).contiguous()
+    for s in range(ticks):
+        b.step(dt, meas[s])
+    sample = np.sort(np.random.default_rng(0).choice(N, 2000, replace=False)).astype(np.uint32)
+    orc = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], p0[sample], dt, dtype=dtype)
+    meas_host = st["meas"][:, :, torch.from_numpy(sample.astype(np.int64)).cuda()].cpu().numpy()   # [ticks,7,2000]
+    if dtype == "f32":
+        meas_host = meas_host.astype(np.float32).astype(np.float64)   # the oracle sees what the kernel saw
+    for s in range(ticks):
+        orc.step(dt, np.ascontiguousarray(meas_host[s].T))
+    check_state(mgr, sample, orc, dtype, "sample of %s" % wl)
+    pose, twist, acc = b.get_est()
+    assert torch.isfinite(pose).all() and torch.isfinite(twist).all() and torch.isfinite(acc).all()
+    np.testing.assert_array_equal(b.slot_ids()[::9973], ids[::9973])
+    tail = np.arange(N - 3000, N, dtype=np.uint32)                    # includes the last, partial tile
+    x, P = mgr.get_state_batch(tail)
+    assert np.isfinite(x).all() and np.isfinite(P).all()
+    sym = np.abs(P - P.transpose(0, 2, 1)).max(axis=(1, 2)) / np.abs(P).max(axis=(1, 2))
+    assert sym.max() < (1e-12 if dtype == "f64" else 1e-4)
+    assert (np.diagonal(P, axis1=1, axis2=2) > 0).all()
+    b.step(dt, None)                                                   # predict only: P grows (A P A^T + Q)
+    _, P2 = mgr.get_state_batch(tail)
+    assert (np.diagonal(P2, axis1=1, axis2=2)[:, :3] >= np.diagonal(P, axis1=1, axis2=2)[:, :3]).all()
+    assert mgr.getNumberMeasurements(int(tail[-1])) == ticks
+    mgr.close()
