@@ -23,6 +23,8 @@ typedef void target_batch_c; /* all targets of one (model, Q, R) inside a manage
 #define TARGET_ANGULAR_VELOCITIES 1
 #define TARGET_UNIFORM_ACCELERATION 2
 #define TARGET_UNIFORM_VELOCITY 3
+/* add to lanes_per_target = 1 to store P symmetric-packed (upper triangle) in HBM */
+#define TARGET_LAYOUT_SYMMETRIC_PACKED 100
 #define TARGET_DTYPE_F64 0
 #define TARGET_DTYPE_F32 1
 
@@ -33,7 +35,10 @@ extern "C" {
 /* ---- construction ---------------------------------------------------------------------- */
 /* file may be NULL (no default model: use the *_typed initialisers, as the reference's
  * default-constructed TargetManager, target_manager.cpp:106-109).  dtype: TARGET_DTYPE_*.
- * lanes_per_target: 0 = the tuned default for (model, dtype); otherwise 1, 2, 3 or 6. */
+ * lanes_per_target: 0 = the tuned default for (model, dtype); otherwise 1, 2, 3 or 6, or
+ * 1 + TARGET_LAYOUT_SYMMETRIC_PACKED (thread per target, upper triangle of P only in HBM: 45 % less
+ * traffic; P is then symmetric by construction, whereas the reference's (I-KC)P is symmetric only to
+ * rounding). */
 target_manager_c* target_manager_new_ex(const char* file, int dtype, int lanes_per_target);
 /* all launches of this manager go to `hip_stream` (a hipStream_t; NULL = default stream) */
 int target_manager_set_stream(target_manager_c* self, void* hip_stream);
@@ -107,7 +112,9 @@ int target_batch_dtype(target_batch_c* b);
 int target_batch_state_dim(target_batch_c* b);
 int target_batch_meas_dim(target_batch_c* b);
 int target_batch_lanes_per_target(target_batch_c* b);
-/* bytes one predict+update cycle of one target must move ((2n + 2n^2 + 7 (+6)) * w) */
+int target_batch_is_symmetric_packed(target_batch_c* b);
+/* bytes one predict+update cycle of one target must move ((2n + 2n^2 + 7 (+6)) * w, or
+ * (2n + n(n+1) + 7 (+6)) * w for a symmetric-packed batch) */
 long target_batch_algorithmic_bytes(target_batch_c* b);
 /* HBM bytes actually allocated per target (record incl. tile padding) */
 double target_batch_resident_bytes_per_target(target_batch_c* b);

@@ -58,7 +58,9 @@ void Batch::synchronize() { TE_HIP_CHECK(hipStreamSynchronize(stream_)); }
 long Batch::algorithmic_bytes_per_cycle() const {
   const long n = ops_->L.n;
   const bool angular = (type_ == ANGULAR_RATES || type_ == ANGULAR_VELOCITIES);
-  return (2 * n + 2 * n * n + 7 + (angular ? 6 : 0)) * (long)elem_size();
+  // full P: 2n + 2n^2 + 7 (+6); symmetric-packed P: 2n + n(n+1) + 7 (+6)
+  const long pwords = ops_->L.packed ? n * (n + 1) : 2 * n * n;
+  return (2 * n + pwords + 7 + (angular ? 6 : 0)) * (long)elem_size();
 }
 
 void Batch::reserve(long n) {

@@ -15,6 +15,7 @@ const Ops* get_ops_av(int dtype, int g) {
     if (g == 0) g = 6;
     switch (g) {
       case 1: return OpsImpl<ModelAV, float, 1>::get();
+      case 101: return OpsImpl<ModelAV, float, 1, true>::get();  // symmetric-packed P
       case 3: return OpsImpl<ModelAV, float, 3>::get();
       case 6: return OpsImpl<ModelAV, float, 6>::get();
       default: return nullptr;

@@ -8,6 +8,7 @@ const Ops* get_ops_ua(int dtype, int g) {
     if (g == 0) g = 3;
     switch (g) {
       case 1: return OpsImpl<ModelUA, double, 1>::get();
+      case 101: return OpsImpl<ModelUA, double, 1, true>::get();  // symmetric-packed P
       case 3: return OpsImpl<ModelUA, double, 3>::get();
       default: return nullptr;
     }
@@ -15,6 +16,7 @@ const Ops* get_ops_ua(int dtype, int g) {
     if (g == 0) g = 1;
     switch (g) {
       case 1: return OpsImpl<ModelUA, float, 1>::get();
+      case 101: return OpsImpl<ModelUA, float, 1, true>::get();  // symmetric-packed P
       case 3: return OpsImpl<ModelUA, float, 3>::get();
       default: return nullptr;
     }

@@ -90,9 +90,9 @@ __device__ __forceinline__ void store_record(char* tb, int lane, const T* rec) {
 
 template <typename T> __device__ __forceinline__ T sel3(int c, T a, T b, T d) { return c == 0 ? a : (c == 1 ? b : d); }
 
-template <class M, typename T, int G, bool INDEXED>
-__global__ void __launch_bounds__((Cfg<M, T, G>::WPB * 64)) kf_step_kernel(const StepArgs<T> a) {
-  using C = Cfg<M, T, G>;
+template <class M, typename T, int G, bool PK, bool INDEXED>
+__global__ void __launch_bounds__((Cfg<M, T, G, PK>::WPB * 64)) kf_step_kernel(const StepArgs<T> a) {
+  using C = Cfg<M, T, G, PK>;
   constexpr int N = C::N, K = C::K, RPL = C::RPL, KPL = C::KPL, TPW = C::TPW, GS = C::GS;
   constexpr int kStepWaves = C::WPB, kStepThreads = C::WPB * 64;
   using F = Mth<T>;
@@ -123,22 +123,36 @@ __global__ void __launch_bounds__((Cfg<M, T, G>::WPB * 64)) kf_step_kernel(const
   }
   char* tb = a.rec + tile * C::TILE_BYTES;
 
-  T rec[C::RW];
+  // `mem` is the HBM image of the record, `rec` the full register image the step works on; they
+  // are the same array unless the batch stores P symmetric-packed.
+  T mem[C::RW];
   if (valid) {
-    load_record<C, T>(tb, lt, rec);
+    load_record<C, T>(tb, lt, mem);
   } else {
 #pragma unroll
-    for (int w = 0; w < C::RW; ++w) rec[w] = 0;
+    for (int w = 0; w < C::RW; ++w) mem[w] = 0;
   }
   T* sQw = s_qr + C::QR_WORDS * wave;
   for (int e = lane; e < C::QR_WORDS; e += 64) sQw[e] = a.qr[e];
   wave_lds_fence();
   const T* sQ = sQw;
   const T* sR = sQw + N * N;
-  // views into the record (compile-time indices only)
+  T rec[C::FRW];
+  if constexpr (PK) {
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+      for (int c = 0; c < N; ++c) rec[r * N + c] = mem[r <= c ? C::tri(r, c) : C::tri(c, r)];
+#pragma unroll
+    for (int w = 0; w < RPL + C::UW; ++w) rec[RPL * N + w] = mem[C::X_OFF + w];
+  } else {
+#pragma unroll
+    for (int w = 0; w < C::RW; ++w) rec[w] = mem[w];
+  }
+  // views into the register image (compile-time indices only)
 #define P_(q, c) rec[(q) * N + (c)]
-#define X_(q) rec[C::X_OFF + (q)]
-#define UW_(s) rec[C::UW_OFF + (s)]
+#define X_(q) rec[RPL * N + (q)]
+#define UW_(s) rec[RPL * N + RPL + (s)]
 
   // per-wave LDS scratch: element `idx` of this lane's target at [idx*GS + g]
   T* sx = s_ex + (C::EX_WORDS > 0 ? C::EX_WORDS : 1) * wave;
@@ -475,7 +489,18 @@ __global__ void __launch_bounds__((Cfg<M, T, G>::WPB * 64)) kf_step_kernel(const
   }
 
   if (valid) {
-    store_record<C, T>(tb, lt, rec);
+    if constexpr (PK) {
+#pragma unroll
+      for (int r = 0; r < N; ++r)
+#pragma unroll
+        for (int c = r; c < N; ++c) mem[C::tri(r, c)] = rec[r * N + c];
+#pragma unroll
+      for (int w = 0; w < RPL + C::UW; ++w) mem[C::X_OFF + w] = rec[RPL * N + w];
+    } else {
+#pragma unroll
+      for (int w = 0; w < C::RW; ++w) mem[w] = rec[w];
+    }
+    store_record<C, T>(tb, lt, mem);
     if (i == 0) {
       if constexpr (INDEXED) {
         const long slot = a.idx[entry];

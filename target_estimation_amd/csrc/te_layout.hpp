@@ -32,9 +32,15 @@ struct ModelAV { static constexpr int TYPE = ANGULAR_VELOCITIES, N = 12, K = 6, 
 constexpr int model_n(int type) { return type == UNIFORM_VELOCITY ? 6 : type == UNIFORM_ACCELERATION ? 9 : type == ANGULAR_RATES ? 18 : 12; }
 constexpr int model_m(int type) { return (type == UNIFORM_VELOCITY || type == UNIFORM_ACCELERATION) ? 3 : 6; }
 
-template <class M, typename T, int G_>
+// PK_ = symmetric-packed storage: only the upper triangle of P (r <= c, row-major) is kept in HBM
+// and mirrored into the registers after the load.  Offered for G = 1 (thread per target), where
+// the mirror is a register rename.  The reference's (I-KC)P is symmetric only to rounding
+// (~1e-16 relative); packed batches keep the owner-row value P[r][c], r <= c, of each pair.
+template <class M, typename T, int G_, bool PK_ = false>
 struct Cfg {
   static constexpr int G = G_;
+  static constexpr bool PK = PK_;
+  static_assert(!PK_ || G_ == 1, "packed storage is implemented for the thread-per-target mapping");
   static constexpr int N = M::N, K = M::K, NB = M::NB;
   static_assert(K % G == 0, "lanes per target must divide the block size");
   static constexpr int RPL = N / G;           // rows of x / P per lane
@@ -42,7 +48,9 @@ struct Cfg {
   static constexpr int TPW = 64 / G;          // targets per wavefront (= per tile)
   static constexpr int LPT = TPW * G;         // active lanes per tile
   static constexpr int UW = M::ANGULAR ? (3 + G - 1) / G : 0;  // unwrap-memory words per lane
-  static constexpr int RW = RPL * (N + 1) + UW;                // record words per lane
+  static constexpr int PW = PK ? N * (N + 1) / 2 : RPL * N;    // words of P per lane in HBM
+  static constexpr int RW = PW + RPL + UW;                     // record words per lane in HBM
+  static constexpr int FRW = RPL * (N + 1) + UW;               // words of the full register image
   static constexpr int VW = 16 / (int)sizeof(T);               // words per 16-byte chunk
   static constexpr int NC = RW / VW;                           // full chunks
   static constexpr int REM = RW % VW;                          // tail words (fp64: 0/1, fp32: 0..3)
@@ -53,8 +61,10 @@ struct Cfg {
   static constexpr long TILE_PAYLOAD = (long)LPT * RW * (long)sizeof(T);
   static constexpr long TILE_BYTES = (TILE_PAYLOAD + 127) / 128 * 128;
   // word offsets inside a record
-  static constexpr int X_OFF = RPL * N;
-  static constexpr int UW_OFF = RPL * N + RPL;
+  static constexpr int X_OFF = PW;
+  static constexpr int UW_OFF = PW + RPL;
+  // upper-triangle index of (r, c), r <= c
+  static constexpr int tri(int r, int c) { return r * N - r * (r - 1) / 2 + (c - r); }
   // LDS exchange words per target (G > 1 only)
   static constexpr int EXA = K * N;                 // top rows of P^- (AV: also the 6 mid rows)
   static constexpr int EXB = K * K;                 // S^-1
@@ -80,7 +90,7 @@ __host__ __device__ inline long record_word_offset(int lane, int w) {
 }
 
 struct LayoutInfo {
-  int n, m, g, tpw, lpt, record_words;
+  int n, m, g, packed, tpw, lpt, record_words;
   long tile_bytes, tile_payload;
 };
 

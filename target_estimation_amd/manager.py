@@ -12,6 +12,7 @@ ANGULAR_RATES, ANGULAR_VELOCITIES, UNIFORM_ACCELERATION, UNIFORM_VELOCITY = 0, 1
 MODEL_TYPES = {"angular_rates": 0, "angular_velocities": 1, "uniform_acceleration": 2, "uniform_velocity": 3}
 MODEL_DIMS = {0: (18, 6), 1: (12, 6), 2: (9, 3), 3: (6, 3)}
 DTYPES = {"f64": 0, "f32": 1}
+SYMMETRIC_PACKED = 100   # add to lanes_per_target=1: upper triangle of P only in HBM
 
 
 def _dp(a):
@@ -50,6 +51,7 @@ class Batch:
     state_dim = property(lambda s: s._lib.target_batch_state_dim(s._h))
     meas_dim = property(lambda s: s._lib.target_batch_meas_dim(s._h))
     lanes_per_target = property(lambda s: s._lib.target_batch_lanes_per_target(s._h))
+    symmetric_packed = property(lambda s: bool(s._lib.target_batch_is_symmetric_packed(s._h)))
     algorithmic_bytes = property(lambda s: s._lib.target_batch_algorithmic_bytes(s._h))
     resident_bytes_per_target = property(lambda s: s._lib.target_batch_resident_bytes_per_target(s._h))
 

@@ -21,10 +21,11 @@ te = pytest.importorskip("target_estimation_amd")
 TOL = {"f64": dict(x_atol=1e-10, x_rtol=1e-10, P_rel=1e-9, out_atol=1e-9),
        "f32": dict(x_atol=2e-3, x_rtol=1e-4, P_rel=2e-3, out_atol=5e-3)}
 
-LANES = {"uniform_velocity": {"f64": [1, 3], "f32": [1, 3]},
-         "uniform_acceleration": {"f64": [1, 3], "f32": [1, 3]},
+# 101 = thread per target with symmetric-packed P in HBM (1 + TARGET_LAYOUT_SYMMETRIC_PACKED)
+LANES = {"uniform_velocity": {"f64": [1, 3, 101], "f32": [1, 3, 101]},
+         "uniform_acceleration": {"f64": [1, 3, 101], "f32": [1, 3, 101]},
          "angular_rates": {"f64": [3, 6], "f32": [2, 3, 6]},
-         "angular_velocities": {"f64": [3, 6], "f32": [1, 3, 6]}}
+         "angular_velocities": {"f64": [3, 6], "f32": [1, 3, 6, 101]}}
 CASES = [(m, d, g) for m in HARNESS_ORDER for d in ("f64", "f32") for g in LANES[m][d]]
 
 
@@ -61,7 +62,8 @@ def test_dense_batch_matches_oracle(models, name, dtype, lanes):
     assert mgr.init_batch(ids, dt, 0.0, p0, v0, a0) == N
     orc = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], p0, dt, 0.0, v0, a0, dtype=dtype)
     b = mgr.batches()[0]
-    assert b.size == N and b.lanes_per_target == lanes and b.state_dim == m["Q"].shape[0]
+    assert b.size == N and b.lanes_per_target == lanes % 100 and b.state_dim == m["Q"].shape[0]
+    assert b.symmetric_packed == (lanes > 100)
     np.testing.assert_array_equal(b.slot_ids(), ids)
     check_state(mgr, ids, orc, dtype, "after init")
     worst = (0.0, 0.0)

@@ -9,8 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-LANES = {"uniform_velocity": {"f64": [1, 3], "f32": [1, 3]}, "uniform_acceleration": {"f64": [1, 3], "f32": [1, 3]},
-         "angular_rates": {"f64": [3, 6], "f32": [2, 3, 6]}, "angular_velocities": {"f64": [3, 6], "f32": [1, 3, 6]}}
+LANES = {"uniform_velocity": {"f64": [1, 3, 101], "f32": [1, 3, 101]}, "uniform_acceleration": {"f64": [1, 3, 101], "f32": [1, 3, 101]},
+         "angular_rates": {"f64": [3, 6], "f32": [2, 3, 6]}, "angular_velocities": {"f64": [3, 6], "f32": [1, 3, 6, 101]}}
 
 
 def main():
@@ -32,7 +32,7 @@ def main():
                     steps = args.steps if n <= 200000 else max(20, args.steps // 5)
                     r = bench.run_workload(te, torch, "_sweep", steps, 10, g, stream_ticks=8)
                     r.pop("_mgr")
-                    print("%-22s %-4s %2d %9d %10.2f %12.4g %9.0f %6.3f" % (model, dtype, g, n, r["device_ms_per_launch"] * 1e3,
+                    print("%-22s %-4s %3d %9d %10.2f %12.4g %9.0f %6.3f" % (model, dtype, g, n, r["device_ms_per_launch"] * 1e3,
                           r["cycles_per_s"], r["achieved_gbs"], r["achieved_gbs"] / 8000.0), flush=True)
                     torch.cuda.empty_cache()
 
