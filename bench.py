@@ -20,13 +20,15 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FULL_P_BYTES = {"uniform_velocity": 91, "uniform_acceleration": 187, "angular_velocities": 325, "angular_rates": 697}  # words, SURVEY 8d
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 # lanes-per-target tuned on MI355X (tools/sweep.py): small, latency-bound batches want more lanes per
 # target, large HBM-bound ones fewer.  0 = the library default.
-# 101 = thread per target + symmetric-packed P in HBM (1 + TARGET_LAYOUT_SYMMETRIC_PACKED).
-TUNED_LANES = {"cfg2": 3, "cfg3": 101, "cfg4ar": 6, "cfg4av": 101, "uv1m": 101, "ua1m": 101, "ar1m": 6, "av1m": 101,
-               "ar1m64": 3, "av1m64": 6, "uv1m_full": 1, "ua1m_full": 1}
+# 0 = automatic: the shipped models' Q, R, P0 do not couple axes, so the library picks the exact
+# axis-separable layout.  The *_full / *_packed workloads force the dense kernel (what general
+# matrices get): full P, or symmetric-packed P (101 = 1 + TARGET_LAYOUT_SYMMETRIC_PACKED).
+TUNED_LANES = {"cfg2_full": 3, "uv1m_full": 1, "ua1m_full": 1, "ar1m_full": 6, "av1m_full": 3, "uv1m_packed": 101}
 
 WORKLOADS = {
     # name: (description, model, dtype, targets per GPU, seed)
@@ -38,8 +40,12 @@ WORKLOADS = {
     "ua1m": ("1000000 targets, uniform-acceleration model, fp32", "uniform_acceleration", "f32", 1_000_000, 20240013),
     "ar1m": ("1000000 targets, angular-rates model, fp32", "angular_rates", "f32", 1_000_000, 20240014),
     "av1m": ("1000000 targets, angular-velocities model, fp32", "angular_velocities", "f32", 1_000_000, 20240015),
-    "uv1m_full": ("1000000 targets, uniform-velocity model, fp64, full (non-packed) P", "uniform_velocity", "f64", 1_000_000, 20240012),
-    "ua1m_full": ("1000000 targets, uniform-acceleration model, fp32, full (non-packed) P", "uniform_acceleration", "f32", 1_000_000, 20240013),
+    "cfg2_full": ("10000 targets, uniform-velocity model, fp64, dense kernel with full P", "uniform_velocity", "f64", 10_000, 20240002),
+    "uv1m_full": ("1000000 targets, uniform-velocity model, fp64, dense kernel with full P", "uniform_velocity", "f64", 1_000_000, 20240012),
+    "uv1m_packed": ("1000000 targets, uniform-velocity model, fp64, dense kernel with symmetric-packed P", "uniform_velocity", "f64", 1_000_000, 20240012),
+    "ua1m_full": ("1000000 targets, uniform-acceleration model, fp32, dense kernel with full P", "uniform_acceleration", "f32", 1_000_000, 20240013),
+    "ar1m_full": ("1000000 targets, angular-rates model, fp32, dense kernel with full P", "angular_rates", "f32", 1_000_000, 20240014),
+    "av1m_full": ("1000000 targets, angular-velocities model, fp32, dense kernel with full P", "angular_velocities", "f32", 1_000_000, 20240015),
     "ar1m64": ("1000000 targets, angular-rates model, fp64", "angular_rates", "f64", 1_000_000, 20240016),
     "av1m64": ("1000000 targets, angular-velocities model, fp64", "angular_velocities", "f64", 1_000_000, 20240017),
 }
@@ -117,7 +123,7 @@ def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None,
     alg_bytes = b.algorithmic_bytes * n_targets
     res = dict(
         name=name, desc=desc, model=model, dtype=dtype, targets_per_gpu=n_targets,
-        lanes_per_target=b.lanes_per_target, symmetric_packed=b.symmetric_packed, elapsed_s=elapsed, ms_per_step=elapsed * 1e3 / steps,
+        lanes_per_target=b.lanes_per_target, layout=b.layout, elapsed_s=elapsed, ms_per_step=elapsed * 1e3 / steps,
         cycles_per_s=n_targets * world * steps / elapsed,
         device_ms_per_launch=launch_s * 1e3,
         algorithmic_bytes_per_cycle=b.algorithmic_bytes, algorithmic_bytes_per_launch=alg_bytes,
@@ -185,7 +191,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--lanes", type=int, default=0, help="lanes per target (0 = tuned default)")
     ap.add_argument("--targets", type=int, default=0, help="override targets per GPU")
-    ap.add_argument("--extra", default="uv1m,ua1m,av1m,ar1m,uv1m_full", help="comma list of extra workloads reported under 'extra' (N=1 only; '' = none)")
+    ap.add_argument("--extra", default="uv1m,ua1m,av1m,ar1m,cfg2_full,uv1m_full,uv1m_packed,ar1m_full", help="comma list of extra workloads reported under 'extra' (N=1 only; '' = none)")
     ap.add_argument("--extra-steps", type=int, default=50)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--launch-mode", default="graph", choices=["python", "sequence", "graph"],
@@ -216,16 +222,26 @@ def main():
         "vs_baseline": None, "dtype": res["dtype"], "data": "synthetic",
         "config": {"workload": res["desc"], "name": res["name"], "model": res["model"],
                    "targets_per_gpu": res["targets_per_gpu"], "targets_total": res["targets_per_gpu"] * world,
-                   "lanes_per_target": res["lanes_per_target"], "symmetric_packed_P": res["symmetric_packed"], "dt": 0.004, "launch_mode": res["launch_mode"],
+                   "lanes_per_target": res["lanes_per_target"], "P_layout": res["layout"], "dt": 0.004, "launch_mode": res["launch_mode"],
                    "sharding": "contiguous id ranges per rank, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": res["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": res["achieved_gbs"] / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "kf_step_kernel<%s,%s,G=%d>" % (res["model"], res["dtype"], res["lanes_per_target"]),
+                     "kernel": ("kf_step_sep_kernel<%s,%s>" % (res["model"], res["dtype"]) if res["layout"] == "axis_separable"
+                                else "kf_step_kernel<%s,%s,G=%d,%s>" % (res["model"], res["dtype"], res["lanes_per_target"], res["layout"])),
+                     "survey_full_P_bytes_per_cycle": FULL_P_BYTES[res["model"]] * (8 if res["dtype"] == "f64" else 4),
                      "algorithmic_bytes_per_cycle": res["algorithmic_bytes_per_cycle"],
                      "algorithmic_bytes_per_launch": res["algorithmic_bytes_per_launch"],
                      "device_ms_per_launch": res["device_ms_per_launch"]},
     }
     del mgr
+    # HBM bytes per launch from the committed rocprofv3 PMC passes (cannot be read inside this process)
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(args.workload)
+        if tr and not args.targets and not args.lanes:
+            out["roofline"]["traffic"] = tr["hbm_read_bytes"] + tr["hbm_write_bytes"]
+            out["roofline"]["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
+    except (OSError, ValueError):
+        pass
     if world == 1 and rank == 0:
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.targets or None)
@@ -233,9 +249,11 @@ def main():
         for name in [e for e in args.extra.split(",") if e]:
             if name == args.workload:
                 continue
-            r = run_workload(te, torch, name, args.extra_steps, 10, 0, launch_mode=args.launch_mode)
+            small = WORKLOADS[name][3] <= 20000
+            r = run_workload(te, torch, name, 1920 if small else args.extra_steps, 64 if small else 10, 0,
+                             launch_mode=args.launch_mode)
             r.pop("_mgr")
-            extras.append({k: r[k] for k in ("name", "desc", "dtype", "targets_per_gpu", "lanes_per_target", "symmetric_packed", "cycles_per_s",
+            extras.append({k: r[k] for k in ("name", "desc", "dtype", "targets_per_gpu", "lanes_per_target", "layout", "cycles_per_s",
                                             "ms_per_step", "device_ms_per_launch", "achieved_gbs",
                                             "algorithmic_bytes_per_cycle")} | {"roofline_frac": r["achieved_gbs"] / HBM_PEAK_GBS})
             torch.cuda.empty_cache()

@@ -25,6 +25,9 @@ typedef void target_batch_c; /* all targets of one (model, Q, R) inside a manage
 #define TARGET_UNIFORM_VELOCITY 3
 /* add to lanes_per_target = 1 to store P symmetric-packed (upper triangle) in HBM */
 #define TARGET_LAYOUT_SYMMETRIC_PACKED 100
+/* lanes_per_target = 1 + this: store only the entries of P inside an axis group (exact when Q, R and
+ * P0 do not couple different axes, as in every shipped model file; refused otherwise) */
+#define TARGET_LAYOUT_AXIS_SEPARABLE 200
 #define TARGET_DTYPE_F64 0
 #define TARGET_DTYPE_F32 1
 
@@ -35,7 +38,9 @@ extern "C" {
 /* ---- construction ---------------------------------------------------------------------- */
 /* file may be NULL (no default model: use the *_typed initialisers, as the reference's
  * default-constructed TargetManager, target_manager.cpp:106-109).  dtype: TARGET_DTYPE_*.
- * lanes_per_target: 0 = the tuned default for (model, dtype); otherwise 1, 2, 3 or 6, or
+ * lanes_per_target: 0 = automatic: the axis-separable layout when the matrices allow it (checked per
+ * init call; see TARGET_LAYOUT_AXIS_SEPARABLE), else the tuned dense default for (model, dtype);
+ * otherwise 1, 2, 3 or 6 (dense, full P), 1 + TARGET_LAYOUT_AXIS_SEPARABLE, or
  * 1 + TARGET_LAYOUT_SYMMETRIC_PACKED (thread per target, upper triangle of P only in HBM: 45 % less
  * traffic; P is then symmetric by construction, whereas the reference's (I-KC)P is symmetric only to
  * rounding). */
@@ -113,8 +118,11 @@ int target_batch_state_dim(target_batch_c* b);
 int target_batch_meas_dim(target_batch_c* b);
 int target_batch_lanes_per_target(target_batch_c* b);
 int target_batch_is_symmetric_packed(target_batch_c* b);
+/* 0 full P, 1 symmetric-packed, 2 axis-separable */
+int target_batch_layout(target_batch_c* b);
 /* bytes one predict+update cycle of one target must move ((2n + 2n^2 + 7 (+6)) * w, or
- * (2n + n(n+1) + 7 (+6)) * w for a symmetric-packed batch) */
+ * (2n + n(n+1) + 7 (+6)) * w for a symmetric-packed batch, (2n + 2 sum(group^2) + 7 (+6)) * w for an
+ * axis-separable one) */
 long target_batch_algorithmic_bytes(target_batch_c* b);
 /* HBM bytes actually allocated per target (record incl. tile padding) */
 double target_batch_resident_bytes_per_target(target_batch_c* b);

@@ -64,6 +64,7 @@ SIGNATURES = {
     "target_batch_meas_dim": (C.c_int, [C.c_void_p]),
     "target_batch_lanes_per_target": (C.c_int, [C.c_void_p]),
     "target_batch_is_symmetric_packed": (C.c_int, [C.c_void_p]),
+    "target_batch_layout": (C.c_int, [C.c_void_p]),
     "target_batch_algorithmic_bytes": (C.c_long, [C.c_void_p]),
     "target_batch_resident_bytes_per_target": (C.c_double, [C.c_void_p]),
     "target_batch_slot_ids": (C.c_long, [C.c_void_p, c_uint_p, C.c_long]),

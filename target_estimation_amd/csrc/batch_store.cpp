@@ -19,7 +19,7 @@ const Ops* get_ops(int type, int dtype, int g) {
 }
 
 Batch::Batch(int type, int dtype, int lanes, const double* Q, const double* R, hipStream_t stream)
-    : type_(type), dtype_(dtype), ops_(get_ops(type, dtype, lanes)), stream_(stream) {
+    : type_(type), dtype_(dtype), lanes_code_(lanes), ops_(get_ops(type, dtype, lanes)), stream_(stream) {
   if (!ops_) throw std::runtime_error("target_estimation_amd: unsupported (model, precision, lanes-per-target) combination");
   const int n = ops_->L.n, m = ops_->L.m;
   Q_.assign(Q, Q + n * n);
@@ -59,7 +59,14 @@ long Batch::algorithmic_bytes_per_cycle() const {
   const long n = ops_->L.n;
   const bool angular = (type_ == ANGULAR_RATES || type_ == ANGULAR_VELOCITIES);
   // full P: 2n + 2n^2 + 7 (+6); symmetric-packed P: 2n + n(n+1) + 7 (+6)
-  const long pwords = ops_->L.packed ? n * (n + 1) : 2 * n * n;
+  long pwords = 2 * n * n;
+  if (ops_->L.layout == LAYOUT_PACKED) pwords = n * (n + 1);
+  if (ops_->L.layout == LAYOUT_SEPARABLE) {
+    // only the entries inside an axis group exist (the others are structural zeros): read + write
+    pwords = 0;
+    for (int r = 0; r < n; ++r)
+      for (int c = 0; c < n; ++c) pwords += group_of(type_, r) == group_of(type_, c) ? 2 : 0;
+  }
   return (2 * n + pwords + 7 + (angular ? 6 : 0)) * (long)elem_size();
 }
 

@@ -21,6 +21,7 @@ class Batch {
   Batch& operator=(const Batch&) = delete;
 
   int type() const { return type_; }
+  int lanes_code() const { return lanes_code_; }
   int dtype() const { return dtype_; }
   int n_state() const { return ops_->L.n; }
   int n_meas() const { return ops_->L.m; }
@@ -85,7 +86,7 @@ class Batch {
   void stage_reserve(long n);
   void upload_slots(const int* slots, long n);
 
-  int type_, dtype_;
+  int type_, dtype_, lanes_code_;
   const Ops* ops_;
   hipStream_t stream_;
   std::vector<double> Q_, R_;

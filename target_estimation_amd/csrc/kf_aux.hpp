@@ -9,17 +9,26 @@
 
 namespace te {
 
-// pointer to element (r, c) of P (c < N) or to x[r] (c == N) of `slot`
+// pointer to element (r, c) of P (c < N) or to x[r] (c == N) of `slot`; nullptr for a
+// structurally zero element of the separable layout
 template <class C, typename T>
 __device__ __forceinline__ T* state_ptr(char* rec, long slot, int r, int c) {
   const long tile = slot / C::TPW;
   const int lane = (int)(slot % C::TPW) * C::G + (r % C::G);
   const int q = (r % C::K) / C::G + (r / C::K) * C::KPL;
-  int w;
-  if (c >= C::N) w = C::X_OFF + q;
-  else if (C::PK) w = (r <= c) ? C::tri(r, c) : C::tri(c, r);
-  else w = q * C::N + c;
+  const int w = (c >= C::N) ? C::X_OFF + q : C::p_word(r, c);
+  if (w < 0) return nullptr;
   return reinterpret_cast<T*>(rec + tile * C::TILE_BYTES + record_word_offset<C, T>(lane, w));
+}
+template <class C, typename T>
+__device__ __forceinline__ T state_get(char* rec, long slot, int r, int c) {
+  const T* p = state_ptr<C, T>(rec, slot, r, c);
+  return p ? *p : (T)0;
+}
+template <class C, typename T>
+__device__ __forceinline__ void state_set(char* rec, long slot, int r, int c, T v) {
+  T* p = state_ptr<C, T>(rec, slot, r, c);
+  if (p) *p = v;
 }
 // pointer to unwrap-memory component cc (0..2) of `slot`
 template <class C, typename T>
@@ -58,9 +67,9 @@ struct InitArgs {
 // angular_rates.cpp:57-65, angular_velocities.cpp:51-56,73 + KalmanFilterInterface::init
 // src/kalman.cpp:16-21 (x = x0, P = P0).  The unwrap memory starts at zero (the reference
 // leaves meas_rpy_internal_ uninitialised: angular_rates.hpp:110, angular_velocities.hpp:127).
-template <class M, typename T, int G, bool PK>
+template <class M, typename T, int G, int LAYOUT>
 __global__ void init_kernel(const InitArgs a) {
-  using C = Cfg<M, T, G, PK>;
+  using C = Cfg<M, T, G, LAYOUT>;
   constexpr int N = C::N;
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= a.n) return;
@@ -91,8 +100,8 @@ __global__ void init_kernel(const InitArgs a) {
   }
   const double* P0 = a.P0 + (a.per_target_P0 ? e * N * N : 0);
   for (int r = 0; r < N; ++r) {
-    *state_ptr<C, T>(a.rec, slot, r, N) = x0[r];
-    for (int c = (C::PK ? r : 0); c < N; ++c) *state_ptr<C, T>(a.rec, slot, r, c) = (T)P0[r * N + c];
+    state_set<C, T>(a.rec, slot, r, N, x0[r]);
+    for (int c = (C::PK ? r : 0); c < N; ++c) state_set<C, T>(a.rec, slot, r, c, (T)P0[r * N + c]);
   }
   if constexpr (M::ANGULAR) {
     for (int cc = 0; cc < 3; ++cc) *unwrap_ptr<C, T>(a.rec, slot, cc) = 0;
@@ -102,42 +111,42 @@ __global__ void init_kernel(const InitArgs a) {
 }
 
 // x [n][N] and P [n][N*N] (row-major, doubles) of the listed slots; one thread per (entry,row)
-template <class M, typename T, int G, bool PK>
+template <class M, typename T, int G, int LAYOUT>
 __global__ void get_state_kernel(char* rec, const int* idx, long n, double* x_out, double* P_out) {
-  using C = Cfg<M, T, G, PK>;
+  using C = Cfg<M, T, G, LAYOUT>;
   constexpr int N = C::N;
   const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= n * N) return;
   const long e = tid / N;
   const int r = (int)(tid % N);
   const long slot = idx ? (long)idx[e] : e;
-  if (x_out) x_out[e * N + r] = (double)*state_ptr<C, T>(rec, slot, r, N);
+  if (x_out) x_out[e * N + r] = (double)state_get<C, T>(rec, slot, r, N);
   if (P_out)
-    for (int c = 0; c < N; ++c) P_out[(e * N + r) * N + c] = (double)*state_ptr<C, T>(rec, slot, r, c);
+    for (int c = 0; c < N; ++c) P_out[(e * N + r) * N + c] = (double)state_get<C, T>(rec, slot, r, c);
 }
 
-template <class M, typename T, int G, bool PK>
+template <class M, typename T, int G, int LAYOUT>
 __global__ void set_state_kernel(char* rec, const int* idx, long n, const double* x_in, const double* P_in,
                                  const double* uw_in) {
-  using C = Cfg<M, T, G, PK>;
+  using C = Cfg<M, T, G, LAYOUT>;
   constexpr int N = C::N;
   const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= n * N) return;
   const long e = tid / N;
   const int r = (int)(tid % N);
   const long slot = idx ? (long)idx[e] : e;
-  if (x_in) *state_ptr<C, T>(rec, slot, r, N) = (T)x_in[e * N + r];
+  if (x_in) state_set<C, T>(rec, slot, r, N, (T)x_in[e * N + r]);
   if (P_in)
-    for (int c = (C::PK ? r : 0); c < N; ++c) *state_ptr<C, T>(rec, slot, r, c) = (T)P_in[(e * N + r) * N + c];
+    for (int c = (C::PK ? r : 0); c < N; ++c) state_set<C, T>(rec, slot, r, c, (T)P_in[(e * N + r) * N + c]);
   if constexpr (M::ANGULAR) {
     if (uw_in && r < 3) *unwrap_ptr<C, T>(rec, slot, r) = (T)uw_in[e * 3 + r];
   }
 }
 
 // copy the whole record of slot `src` over slot `dst` (erase = swap-with-last compaction)
-template <class M, typename T, int G, bool PK>
+template <class M, typename T, int G, int LAYOUT>
 __global__ void move_record_kernel(char* rec, long src, long dst, double* t_base, int* nm_base) {
-  using C = Cfg<M, T, G, PK>;
+  using C = Cfg<M, T, G, LAYOUT>;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= C::G * C::RW) return;
   const int i = tid / C::RW, w = tid % C::RW;
@@ -246,16 +255,16 @@ __device__ __forceinline__ void derive_outputs(const T* x, bool at_time, T d, T*
   }
 }
 
-template <class M, typename T, int G, bool PK>
+template <class M, typename T, int G, int LAYOUT>
 __global__ void outputs_kernel(const OutArgs a) {
-  using C = Cfg<M, T, G, PK>;
+  using C = Cfg<M, T, G, LAYOUT>;
   constexpr int N = C::N;
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= a.n) return;
   const long slot = a.idx ? (long)a.idx[e] : e;
   T x[N];
 #pragma unroll
-  for (int r = 0; r < N; ++r) x[r] = *state_ptr<C, T>(a.rec, slot, r, N);
+  for (int r = 0; r < N; ++r) x[r] = state_get<C, T>(a.rec, slot, r, N);
   T d = 0;
   if (a.at_time) d = (a.t1 != a.t1) ? (T)0 : (T)(a.t1 - (a.t_base[slot] + a.t_acc));
   T pose7[7], twist6[6], acc6[6];
@@ -281,16 +290,16 @@ struct IntersectArgs {
 // IntersectionSolver::getIntersectionTimeWithSphere / getIntersectionPoseWithSphere without the
 // moving-average convergence gate (src/intersection_solver.cpp:42-104): quartic in delta from the
 // extrapolated (p, v, a) at t1, smallest real root, pose at t1 + delta.
-template <class M, typename T, int G, bool PK>
+template <class M, typename T, int G, int LAYOUT>
 __global__ void intersect_kernel(const IntersectArgs a) {
-  using C = Cfg<M, T, G, PK>;
+  using C = Cfg<M, T, G, LAYOUT>;
   constexpr int N = C::N;
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= a.n) return;
   const long slot = a.idx ? (long)a.idx[e] : e;
   T x[N];
 #pragma unroll
-  for (int r = 0; r < N; ++r) x[r] = *state_ptr<C, T>(a.rec, slot, r, N);
+  for (int r = 0; r < N; ++r) x[r] = state_get<C, T>(a.rec, slot, r, N);
   const double t = a.t_base[slot] + a.t_acc;
   const double t1 = (a.t1 != a.t1) ? t : a.t1;
   T pose7[7], twist6[6], acc6[6];

@@ -9,6 +9,7 @@ const Ops* get_ops_ar(int dtype, int g) {
     switch (g) {
       case 3: return OpsImpl<ModelAR, double, 3>::get();
       case 6: return OpsImpl<ModelAR, double, 6>::get();
+      case 201: return OpsImpl<ModelAR, double, 1, LAYOUT_SEPARABLE>::get();  // axis-separable
       default: return nullptr;
     }
   } else if (dtype == F32) {
@@ -17,6 +18,7 @@ const Ops* get_ops_ar(int dtype, int g) {
       case 2: return OpsImpl<ModelAR, float, 2>::get();
       case 3: return OpsImpl<ModelAR, float, 3>::get();
       case 6: return OpsImpl<ModelAR, float, 6>::get();
+      case 201: return OpsImpl<ModelAR, float, 1, LAYOUT_SEPARABLE>::get();  // axis-separable
       default: return nullptr;
     }
   }

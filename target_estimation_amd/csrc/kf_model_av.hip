@@ -9,15 +9,17 @@ const Ops* get_ops_av(int dtype, int g) {
     switch (g) {
       case 3: return OpsImpl<ModelAV, double, 3>::get();
       case 6: return OpsImpl<ModelAV, double, 6>::get();
+      case 201: return OpsImpl<ModelAV, double, 1, LAYOUT_SEPARABLE>::get();  // axis-separable
       default: return nullptr;
     }
   } else if (dtype == F32) {
     if (g == 0) g = 6;
     switch (g) {
       case 1: return OpsImpl<ModelAV, float, 1>::get();
-      case 101: return OpsImpl<ModelAV, float, 1, true>::get();  // symmetric-packed P
+      case 101: return OpsImpl<ModelAV, float, 1, LAYOUT_PACKED>::get();  // symmetric-packed P
       case 3: return OpsImpl<ModelAV, float, 3>::get();
       case 6: return OpsImpl<ModelAV, float, 6>::get();
+      case 201: return OpsImpl<ModelAV, float, 1, LAYOUT_SEPARABLE>::get();  // axis-separable
       default: return nullptr;
     }
   }

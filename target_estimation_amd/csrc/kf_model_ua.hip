@@ -8,16 +8,18 @@ const Ops* get_ops_ua(int dtype, int g) {
     if (g == 0) g = 3;
     switch (g) {
       case 1: return OpsImpl<ModelUA, double, 1>::get();
-      case 101: return OpsImpl<ModelUA, double, 1, true>::get();  // symmetric-packed P
+      case 101: return OpsImpl<ModelUA, double, 1, LAYOUT_PACKED>::get();  // symmetric-packed P
       case 3: return OpsImpl<ModelUA, double, 3>::get();
+      case 201: return OpsImpl<ModelUA, double, 1, LAYOUT_SEPARABLE>::get();  // axis-separable
       default: return nullptr;
     }
   } else if (dtype == F32) {
     if (g == 0) g = 1;
     switch (g) {
       case 1: return OpsImpl<ModelUA, float, 1>::get();
-      case 101: return OpsImpl<ModelUA, float, 1, true>::get();  // symmetric-packed P
+      case 101: return OpsImpl<ModelUA, float, 1, LAYOUT_PACKED>::get();  // symmetric-packed P
       case 3: return OpsImpl<ModelUA, float, 3>::get();
+      case 201: return OpsImpl<ModelUA, float, 1, LAYOUT_SEPARABLE>::get();  // axis-separable
       default: return nullptr;
     }
   }

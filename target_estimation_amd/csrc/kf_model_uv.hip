@@ -8,16 +8,18 @@ const Ops* get_ops_uv(int dtype, int g) {
     if (g == 0) g = 3;
     switch (g) {
       case 1: return OpsImpl<ModelUV, double, 1>::get();
-      case 101: return OpsImpl<ModelUV, double, 1, true>::get();  // symmetric-packed P
+      case 101: return OpsImpl<ModelUV, double, 1, LAYOUT_PACKED>::get();  // symmetric-packed P
       case 3: return OpsImpl<ModelUV, double, 3>::get();
+      case 201: return OpsImpl<ModelUV, double, 1, LAYOUT_SEPARABLE>::get();  // axis-separable
       default: return nullptr;
     }
   } else if (dtype == F32) {
     if (g == 0) g = 3;
     switch (g) {
       case 1: return OpsImpl<ModelUV, float, 1>::get();
-      case 101: return OpsImpl<ModelUV, float, 1, true>::get();  // symmetric-packed P
+      case 101: return OpsImpl<ModelUV, float, 1, LAYOUT_PACKED>::get();  // symmetric-packed P
       case 3: return OpsImpl<ModelUV, float, 3>::get();
+      case 201: return OpsImpl<ModelUV, float, 1, LAYOUT_SEPARABLE>::get();  // axis-separable
       default: return nullptr;
     }
   }

@@ -3,12 +3,13 @@
 #pragma once
 #include "kf_ops.hpp"
 #include "kf_step.hpp"
+#include "kf_step_sep.hpp"
 
 namespace te {
 
-template <class M, typename T, int G, bool PK = false>
+template <class M, typename T, int G, int LAYOUT = LAYOUT_FULL>
 struct OpsImpl {
-  using C = Cfg<M, T, G, PK>;
+  using C = Cfg<M, T, G, LAYOUT>;
 
   static void step(const StepParams& p, hipStream_t s) {
     if (p.n <= 0) return;
@@ -18,32 +19,40 @@ struct OpsImpl {
     a.dt_per = p.dt_per; a.dt = p.dt; a.t_base = p.t_base; a.nm_base = p.nm_base;
     const long waves = (p.n + C::TPW - 1) / C::TPW;
     const unsigned blocks = (unsigned)((waves + C::WPB - 1) / C::WPB);
-    if (p.idx)
-      hipLaunchKernelGGL((kf_step_kernel<M, T, G, PK, true>), dim3(blocks), dim3(C::WPB * 64), 0, s, a);
-    else
-      hipLaunchKernelGGL((kf_step_kernel<M, T, G, PK, false>), dim3(blocks), dim3(C::WPB * 64), 0, s, a);
+    if constexpr (LAYOUT == LAYOUT_SEPARABLE) {
+      const unsigned b4 = (unsigned)((waves + 3) / 4);
+      if (p.idx)
+        hipLaunchKernelGGL((kf_step_sep_kernel<M, T, true>), dim3(b4), dim3(256), 0, s, a);
+      else
+        hipLaunchKernelGGL((kf_step_sep_kernel<M, T, false>), dim3(b4), dim3(256), 0, s, a);
+    } else {
+      if (p.idx)
+        hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, true>), dim3(blocks), dim3(C::WPB * 64), 0, s, a);
+      else
+        hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, false>), dim3(blocks), dim3(C::WPB * 64), 0, s, a);
+    }
   }
   static void init(const InitArgs& a, hipStream_t s) {
     if (a.n <= 0) return;
-    hipLaunchKernelGGL((init_kernel<M, T, G, PK>), dim3((unsigned)((a.n + 127) / 128)), dim3(128), 0, s, a);
+    hipLaunchKernelGGL((init_kernel<M, T, G, LAYOUT>), dim3((unsigned)((a.n + 127) / 128)), dim3(128), 0, s, a);
   }
   static void get_state(char* rec, const int* idx, long n, double* x, double* P, hipStream_t s) {
     if (n <= 0) return;
     const long th = n * C::N;
-    hipLaunchKernelGGL((get_state_kernel<M, T, G, PK>), dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, rec, idx, n, x, P);
+    hipLaunchKernelGGL((get_state_kernel<M, T, G, LAYOUT>), dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, rec, idx, n, x, P);
   }
   static void set_state(char* rec, const int* idx, long n, const double* x, const double* P, const double* uw, hipStream_t s) {
     if (n <= 0) return;
     const long th = n * C::N;
-    hipLaunchKernelGGL((set_state_kernel<M, T, G, PK>), dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, rec, idx, n, x, P, uw);
+    hipLaunchKernelGGL((set_state_kernel<M, T, G, LAYOUT>), dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, rec, idx, n, x, P, uw);
   }
   static void move_record(char* rec, long src, long dst, double* t_base, int* nm_base, hipStream_t s) {
     const int th = C::G * C::RW;
-    hipLaunchKernelGGL((move_record_kernel<M, T, G, PK>), dim3((th + 255) / 256), dim3(256), 0, s, rec, src, dst, t_base, nm_base);
+    hipLaunchKernelGGL((move_record_kernel<M, T, G, LAYOUT>), dim3((th + 255) / 256), dim3(256), 0, s, rec, src, dst, t_base, nm_base);
   }
   static void outputs(const OutArgs& a, hipStream_t s) {
     if (a.n <= 0) return;
-    hipLaunchKernelGGL((outputs_kernel<M, T, G, PK>), dim3((unsigned)((a.n + 127) / 128)), dim3(128), 0, s, a);
+    hipLaunchKernelGGL((outputs_kernel<M, T, G, LAYOUT>), dim3((unsigned)((a.n + 127) / 128)), dim3(128), 0, s, a);
   }
   static void pack_meas(const double* aos, long n, void* soa, long ld, hipStream_t s) {
     if (n <= 0) return;
@@ -51,11 +60,11 @@ struct OpsImpl {
   }
   static void intersect(const IntersectArgs& a, hipStream_t s) {
     if (a.n <= 0) return;
-    hipLaunchKernelGGL((intersect_kernel<M, T, G, PK>), dim3((unsigned)((a.n + 63) / 64)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL((intersect_kernel<M, T, G, LAYOUT>), dim3((unsigned)((a.n + 63) / 64)), dim3(64), 0, s, a);
   }
   static const Ops* get() {
     static const Ops ops = {
-        LayoutInfo{C::N, C::K, G, PK ? 1 : 0, C::TPW, C::LPT, C::RW, C::TILE_BYTES, C::TILE_PAYLOAD},
+        LayoutInfo{C::N, C::K, G, LAYOUT, C::TPW, C::LPT, C::RW, C::TILE_BYTES, C::TILE_PAYLOAD},
         C::WPB, &step, &init, &get_state, &set_state, &move_record, &outputs, &pack_meas, &intersect};
     return &ops;
   }

@@ -90,9 +90,11 @@ __device__ __forceinline__ void store_record(char* tb, int lane, const T* rec) {
 
 template <typename T> __device__ __forceinline__ T sel3(int c, T a, T b, T d) { return c == 0 ? a : (c == 1 ? b : d); }
 
-template <class M, typename T, int G, bool PK, bool INDEXED>
-__global__ void __launch_bounds__((Cfg<M, T, G, PK>::WPB * 64)) kf_step_kernel(const StepArgs<T> a) {
-  using C = Cfg<M, T, G, PK>;
+template <class M, typename T, int G, int LAYOUT, bool INDEXED>
+__global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kernel(const StepArgs<T> a) {
+  using C = Cfg<M, T, G, LAYOUT>;
+  constexpr bool PK = C::PK;
+  static_assert(!C::SEP, "the separable layout has its own kernel (kf_step_sep.hpp)");
   constexpr int N = C::N, K = C::K, RPL = C::RPL, KPL = C::KPL, TPW = C::TPW, GS = C::GS;
   constexpr int kStepWaves = C::WPB, kStepThreads = C::WPB * 64;
   using F = Mth<T>;

@@ -1,0 +1,327 @@
+// kf_step_sep.hpp -- predict+update for axis-separable batches (LAYOUT_SEPARABLE).
+//
+// When Q, R and P0 have no entries between different axis groups (te_layout.hpp, group_of) the
+// dense filter of src/kalman.cpp:84-95 / :129-140 never creates any: every product that would
+// touch such an entry multiplies an exact zero.  The step below is therefore the SAME arithmetic
+// as kf_step.hpp with the structurally zero terms left out:
+//   linear models : one [p v (a)] filter with a scalar measurement per axis
+//                   (uniform_velocity 3 x 2 states, uniform_acceleration 3 x 3, angular_rates 6 x 3);
+//   EKF           : three [p v] filters for x, y, z and one 6-state [rpy, omega] EKF with the
+//                   3-vector Euler-angle measurement (Jacobians of angular_velocities.cpp:116-124).
+// Per target the record shrinks from n^2 + n to sum(group^2) + n words (angular_rates: 345 -> 75),
+// which is what makes this worth a kernel: the step is HBM-bound.  Thread per target, everything
+// in registers, no LDS; Q and R are read through the scalar cache (uniform addresses).
+// The host only selects this layout after checking the matrices (target_manager.cpp,
+// is_axis_separable); general matrices use the dense kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kf_step.hpp"
+
+namespace te {
+
+// one [p v (a)] chain with a scalar position measurement: rows r0, r0+K, r0+2K of the model
+template <int NB, typename T>
+__device__ __forceinline__ void sep_linear_axis(T* x, T (&P)[NB][NB], const T (&Q)[NB][NB], T r_meas, T dt, bool has, T y) {
+#pragma clang fp contract(off)  // only the explicit fma calls fuse: same roundings as the dense kernel
+  using F = Mth<T>;
+  const T hdt = (T)0.5 * dt * dt;
+  // x^- = A x ; AP = A P (rows)
+#pragma unroll
+  for (int b = 0; b + 1 < NB; ++b) {
+    x[b] = F::fma(dt, x[b + 1], x[b]);
+    if (NB == 3 && b == 0) x[b] = F::fma(hdt, x[b + 2], x[b]);
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      T v = F::fma(dt, P[b + 1][c], P[b][c]);
+      if (NB == 3 && b == 0) v = F::fma(hdt, P[b + 2][c], v);
+      P[b][c] = v;
+    }
+  }
+  // (AP) A^T (columns), + Q
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      T v = P[b][c];
+      if (c + 1 < NB) {
+        v = F::fma(dt, P[b][c + 1], v);
+        if (NB == 3 && c == 0) v = F::fma(hdt, P[b][c + 2], v);
+      }
+      P[b][c] = v + Q[b][c];
+    }
+  if (!has) return;
+  // S = P00 + R ; K = P[:,0] / S ; x += K (y - x0) ; P = (I - K C) P
+  const T inv = (T)1 / (P[0][0] + r_meas);
+  T Kg[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) Kg[b] = P[b][0] * inv;
+  const T nu = y - x[0];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) x[b] += Kg[b] * nu;
+  T top[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) top[c] = P[0][c];
+  const T d0 = (T)1 - Kg[0];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    P[0][c] = d0 * top[c];
+#pragma unroll
+    for (int b = 1; b < NB; ++b) {
+      const T t = ((T)0 - Kg[b]) * top[c];
+      P[b][c] = t + P[b][c];
+    }
+  }
+}
+
+template <class M, typename T, bool INDEXED>
+__global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
+  using C = Cfg<M, T, 1, LAYOUT_SEPARABLE>;
+  constexpr int N = C::N, K = C::K, NB = C::NB, TPW = C::TPW;
+  using F = Mth<T>;
+
+  const int lane = threadIdx.x & 63;
+  const long wg = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (wg * TPW >= a.n) return;
+  const long entry = wg * TPW + lane;
+  const bool valid = entry < a.n;
+  long tile;
+  int lt;
+  if constexpr (INDEXED) {
+    const long slot = valid ? (long)a.idx[entry] : 0;
+    tile = slot / TPW;
+    lt = (int)(slot % TPW);
+  } else {
+    tile = wg;
+    lt = lane;
+  }
+  char* tb = a.rec + tile * C::TILE_BYTES;
+  T mem[C::RW];
+  if (valid) {
+    load_record<C, T>(tb, lt, mem);
+  } else {
+#pragma unroll
+    for (int w = 0; w < C::RW; ++w) mem[w] = 0;
+  }
+  double dtd = a.dt;
+  if constexpr (INDEXED) {
+    if (a.dt_per && valid) dtd = a.dt_per[entry];
+  }
+  const T dt = (T)dtd;
+  const bool has = valid && a.meas != nullptr && (a.has_meas == nullptr || a.has_meas[entry] != 0);
+  const T* Qm = a.qr;
+  const T* Rm = a.qr + N * N;
+
+  T mrpy[3] = {0, 0, 0};
+  if constexpr (M::ANGULAR) {
+    if (has) {
+      T q[4];
+      q[0] = a.meas[3 * a.meas_ld + entry];
+      q[1] = a.meas[4 * a.meas_ld + entry];
+      q[2] = a.meas[5 * a.meas_ld + entry];
+      q[3] = a.meas[6 * a.meas_ld + entry];
+      quat_normalize(q);
+      quat_to_rpy(q, mrpy);
+    }
+  }
+#define XW_(r) mem[C::X_OFF + (r)]
+#define UWW_(s) mem[C::UW_OFF + (s)]
+
+  // ---- the [p v (a)] chains.  Linear models: K of them, rows {i, i+K, i+2K}.  EKF: x, y, z with
+  // rows {i, i+6} (position, velocity).
+  constexpr int NLIN = M::EKF ? 3 : K;
+  constexpr int LB = M::EKF ? 2 : NB;         // states per chain
+  constexpr int STRIDE = M::EKF ? 6 : K;      // row distance between the states of a chain
+#pragma unroll
+  for (int i = 0; i < NLIN; ++i) {
+    T xs[LB], Pb[LB][LB], Qb[LB][LB];
+#pragma unroll
+    for (int b = 0; b < LB; ++b) {
+      xs[b] = XW_(i + STRIDE * b);
+#pragma unroll
+      for (int c = 0; c < LB; ++c) {
+        Pb[b][c] = mem[C::PWORD.v[i + STRIDE * b][i + STRIDE * c]];
+        Qb[b][c] = Qm[(i + STRIDE * b) * N + (i + STRIDE * c)];
+      }
+    }
+    T y = 0;
+    if (has) {
+      if (!M::ANGULAR || i < 3) {
+        y = a.meas[(long)i * a.meas_ld + entry];
+      } else {
+        y = unwrap_angle(UWW_(i - 3), mrpy[i - 3]);   // angular_rates.cpp:85-88
+        UWW_(i - 3) = y;
+      }
+    }
+    sep_linear_axis<LB, T>(xs, Pb, Qb, Rm[i * K + i], dt, has, y);
+#pragma unroll
+    for (int b = 0; b < LB; ++b) {
+      XW_(i + STRIDE * b) = xs[b];
+#pragma unroll
+      for (int c = 0; c < LB; ++c) mem[C::PWORD.v[i + STRIDE * b][i + STRIDE * c]] = Pb[b][c];
+    }
+  }
+
+  // ---- EKF attitude group: local rows 0..2 = rpy (global 3..5), 3..5 = omega (global 9..11)
+  if constexpr (M::EKF) {
+    constexpr int GR[6] = {3, 4, 5, 9, 10, 11};
+    T xr[6], Pr[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      xr[r] = XW_(GR[r]);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) Pr[r][c] = mem[C::PWORD.v[GR[r]][GR[c]]];
+    }
+    T s_r, c_r, s_p, c_p;
+    F::sincos(xr[0], &s_r, &c_r);
+    F::sincos(xr[1], &s_p, &c_p);
+    const T wy = xr[4], wz = xr[5];
+    // geometry.hpp:394-426 (Jacobians at the previous posterior), :359-374 (EarBaseInv)
+    T Jr[3][3], Jw[3][3], Ei[3][3];
+    Jr[0][0] = (dt * (wy * c_r * s_p - wz * s_p * s_r)) / c_p + 1;
+    Jr[0][1] = (dt * (wz * c_r + wy * s_r)) / (c_p * c_p);
+    Jr[0][2] = 0;
+    Jr[1][0] = -dt * (wz * c_r + wy * s_r);
+    Jr[1][1] = 1;
+    Jr[1][2] = 0;
+    Jr[2][0] = (dt * (wy * c_r - wz * s_r)) / c_p;
+    Jr[2][1] = (dt * s_p * (wz * c_r + wy * s_r)) / (c_p * c_p);
+    Jr[2][2] = 1;
+    Jw[0][0] = dt; Jw[0][1] = (dt * s_p * s_r) / c_p; Jw[0][2] = (dt * c_r * s_p) / c_p;
+    Jw[1][0] = 0;  Jw[1][1] = dt * c_r;               Jw[1][2] = -dt * s_r;
+    Jw[2][0] = 0;  Jw[2][1] = (dt * s_r) / c_p;       Jw[2][2] = (dt * c_r) / c_p;
+    Ei[0][0] = 1; Ei[0][1] = (s_p * s_r) / c_p; Ei[0][2] = (c_r * s_p) / c_p;
+    Ei[1][0] = 0; Ei[1][1] = c_r;               Ei[1][2] = -s_r;
+    Ei[2][0] = 0; Ei[2][1] = s_r / c_p;         Ei[2][2] = c_r / c_p;
+    // x^- = f(x): rpy += dt * EarBaseInv(rpy) * omega  (angular_velocities.cpp:137)
+    {
+      T nr[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        T acc = (dt * Ei[c][0]) * xr[3];
+        acc = F::fma(dt * Ei[c][1], xr[4], acc);
+        acc = F::fma(dt * Ei[c][2], xr[5], acc);
+        nr[c] = xr[c] + acc;
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) xr[c] = nr[c];
+    }
+    // A P: rows 0..2 = Jr P[0:3,:] + Jw P[3:6,:]; rows 3..5 unchanged
+    {
+      T np[3][6];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          T v = Jr[r][0] * Pr[0][c];
+          v = F::fma(Jr[r][1], Pr[1][c], v);
+          v = F::fma(Jr[r][2], Pr[2][c], v);
+          v = F::fma(Jw[r][0], Pr[3][c], v);
+          v = F::fma(Jw[r][1], Pr[4][c], v);
+          v = F::fma(Jw[r][2], Pr[5][c], v);
+          np[r][c] = v;
+        }
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) Pr[r][c] = np[r][c];
+    }
+    // (A P) A^T: columns 0..2, then + Q
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      T nw[3];
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        T v = Pr[r][0] * Jr[cc][0];
+        v = F::fma(Pr[r][1], Jr[cc][1], v);
+        v = F::fma(Pr[r][2], Jr[cc][2], v);
+        v = F::fma(Pr[r][3], Jw[cc][0], v);
+        v = F::fma(Pr[r][4], Jw[cc][1], v);
+        v = F::fma(Pr[r][5], Jw[cc][2], v);
+        nw[cc] = v;
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) Pr[r][c] = (c < 3 ? nw[c < 3 ? c : 0] : Pr[r][c]) + Qm[GR[r] * N + GR[c]];
+    }
+    if (has) {
+      T S[3][3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) S[r][c] = Pr[r][c] + Rm[(3 + r) * K + (3 + c)];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const T inv = (T)1 / S[p][p];
+        S[p][p] = 1;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) S[p][c] *= inv;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          if (r == p) continue;
+          const T f = S[r][p];
+          S[r][p] = 0;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) S[r][c] = F::fma(-f, S[p][c], S[r][c]);
+        }
+      }
+      T nu[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const T y = unwrap_angle(UWW_(c), mrpy[c]);   // angular_velocities.cpp:93-96
+        UWW_(c) = y;
+        nu[c] = y - xr[c];
+      }
+      T Kg[6][3];
+#pragma unroll
+      for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int r = 0; r < 6; ++r) Kg[r][l] = (c == 0) ? Pr[r][0] * S[0][l] : F::fma(Pr[r][c], S[c][l], Kg[r][l]);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        T acc = Kg[r][0] * nu[0];
+        acc = F::fma(Kg[r][1], nu[1], acc);
+        acc = F::fma(Kg[r][2], nu[2], acc);
+        xr[r] += acc;
+      }
+      T D[6][3];
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) D[r][j] = ((r == j) ? (T)1 : (T)0) - Kg[r][j];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const T t0 = Pr[0][c], t1 = Pr[1][c], t2 = Pr[2][c];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          T acc = D[r][0] * t0;
+          acc = F::fma(D[r][1], t1, acc);
+          acc = F::fma(D[r][2], t2, acc);
+          Pr[r][c] = (r < 3) ? acc : acc + Pr[r][c];
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      XW_(GR[r]) = xr[r];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) mem[C::PWORD.v[GR[r]][GR[c]]] = Pr[r][c];
+    }
+  }
+
+  if (valid) {
+    store_record<C, T>(tb, lt, mem);
+    if constexpr (INDEXED) {
+      const long slot = a.idx[entry];
+      a.t_base[slot] += dtd;
+      if (has) a.nm_base[slot] += 1;
+    } else {
+      if (a.has_meas != nullptr && has) a.nm_base[entry] += 1;
+    }
+  }
+#undef XW_
+#undef UWW_
+}
+
+}  // namespace te

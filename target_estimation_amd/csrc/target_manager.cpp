@@ -79,10 +79,34 @@ bool TargetManager::loadYamlFile(const std::string& file, std::vector<double>& Q
   return success;
 }
 
-int TargetManager::findOrCreateBatch(int type, const double* Q, const double* R) {
+bool is_axis_separable(int type, const double* Q, const double* R, const double* P0, long n_P0) {
+  const int n = model_n(type), m = model_m(type);
+  for (int r = 0; r < n; ++r)
+    for (int c = 0; c < n; ++c) {
+      if (group_of(type, r) == group_of(type, c)) continue;
+      if (Q[r * n + c] != 0.0) return false;
+      for (long k = 0; k < n_P0; ++k)
+        if (P0[k * n * n + r * n + c] != 0.0) return false;
+    }
+  for (int r = 0; r < m; ++r)
+    for (int c = 0; c < m; ++c)
+      if (group_of(type, r) != group_of(type, c) && R[r * m + c] != 0.0) return false;
+  return true;
+}
+
+int TargetManager::chooseLayout(int type, const double* Q, const double* R, const double* P0, long n_P0) const {
+  constexpr int kSeparable = 201;  // 1 + TARGET_LAYOUT_AXIS_SEPARABLE
+  const bool sep = is_axis_separable(type, Q, R, P0, n_P0);
+  if (lanes_ == 0) return sep ? kSeparable : 0;
+  if (lanes_ == kSeparable && !sep)
+    throw std::runtime_error("target_estimation_amd: the axis-separable layout was requested but Q, R or P0 couple different axes");
+  return lanes_;
+}
+
+int TargetManager::findOrCreateBatch(int type, const double* Q, const double* R, int lanes_code) {
   for (size_t b = 0; b < batches_.size(); ++b)
-    if (batches_[b]->same_params(type, Q, R)) return (int)b;
-  batches_.emplace_back(new Batch(type, dtype_, lanes_, Q, R, stream_));
+    if (batches_[b]->same_params(type, Q, R) && batches_[b]->lanes_code() == lanes_code) return (int)b;
+  batches_.emplace_back(new Batch(type, dtype_, lanes_code, Q, R, stream_));
   return (int)batches_.size() - 1;
 }
 
@@ -125,7 +149,7 @@ void TargetManager::init(target_t type, unsigned id, double dt0, double t0, cons
   (void)dt0;  // only shapes the constructor's A, which every step rebuilds (uniform_velocity.cpp:40,67)
   lock_guard<mutex> lg(target_lock_);
   if (targets_.find(id) == targets_.end()) {
-    const int b = findOrCreateBatch((int)type, Q, R);
+    const int b = findOrCreateBatch((int)type, Q, R, chooseLayout((int)type, Q, R, P0, 1));
     const long slot = batches_[(size_t)b]->append(1, &id, t0, P0, false, p0, v0 ? v0 : kZero6, a0 ? a0 : kZero6);
     targets_[id] = Loc{b, (int)slot};
     if (verbose_) {
@@ -176,7 +200,7 @@ long TargetManager::initBatch(target_t type, const unsigned* ids, long n, double
   }
   if (keep.empty()) return 0;
   const long k = (long)keep.size();
-  const int b = findOrCreateBatch((int)type, Q, R);
+  const int b = findOrCreateBatch((int)type, Q, R, chooseLayout((int)type, Q, R, P0, per_target_P0 ? n : 1));
   long first;
   if (k == n) {
     first = batches_[(size_t)b]->append(n, ids, t0, P0, per_target_P0, p0, v0, a0);

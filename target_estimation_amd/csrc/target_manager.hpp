@@ -26,6 +26,9 @@
 
 namespace te {
 
+// true if Q, R and the n_P0 covariances have no entry between different axis groups (te_layout.hpp)
+bool is_axis_separable(int type, const double* Q, const double* R, const double* P0, long n_P0);
+
 class TargetManager {
  public:
   typedef std::shared_ptr<TargetManager> Ptr;
@@ -98,7 +101,10 @@ class TargetManager {
   struct Loc { int batch; int slot; };
   bool loadYamlFile(const std::string& file, std::vector<double>& Q, std::vector<double>& R, std::vector<double>& P,
                     target_t& type);  // target_manager.cpp:67-104
-  int findOrCreateBatch(int type, const double* Q, const double* R);
+  // lanes code of a new target's batch: the manager's explicit choice, or (auto) the axis-separable
+  // layout when Q, R and every P0 allow it
+  int chooseLayout(int type, const double* Q, const double* R, const double* P0, long n_P0) const;
+  int findOrCreateBatch(int type, const double* Q, const double* R, int lanes_code);
   bool find(unsigned id, Loc& loc);
 
   std::map<unsigned, Loc> targets_;

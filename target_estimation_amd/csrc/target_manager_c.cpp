@@ -246,7 +246,8 @@ int target_batch_dtype(target_batch_c* b) { return B(b)->dtype(); }
 int target_batch_state_dim(target_batch_c* b) { return B(b)->n_state(); }
 int target_batch_meas_dim(target_batch_c* b) { return B(b)->n_meas(); }
 int target_batch_lanes_per_target(target_batch_c* b) { return B(b)->layout().g; }
-int target_batch_is_symmetric_packed(target_batch_c* b) { return B(b)->layout().packed; }
+int target_batch_is_symmetric_packed(target_batch_c* b) { return B(b)->layout().layout == te::LAYOUT_PACKED; }
+int target_batch_layout(target_batch_c* b) { return B(b)->layout().layout; }
 long target_batch_algorithmic_bytes(target_batch_c* b) { return B(b)->algorithmic_bytes_per_cycle(); }
 double target_batch_resident_bytes_per_target(target_batch_c* b) {
   return (double)B(b)->layout().tile_bytes / (double)B(b)->layout().tpw;

@@ -24,10 +24,26 @@ namespace te {
 enum ModelType : int { ANGULAR_RATES = 0, ANGULAR_VELOCITIES = 1, UNIFORM_ACCELERATION = 2, UNIFORM_VELOCITY = 3 };
 enum DType : int { F64 = 0, F32 = 1 };
 
+// Axis groups: the sets of state rows that the model's transition and measurement couple.  The
+// linear models move every axis (x, y, z, roll, pitch, yaw) independently (A = I + dt E_K + ...
+// only links rows r, r+K, r+2K); the EKF links the three Euler angles and the three body rates
+// through its Jacobian (angular_velocities.cpp:116-124) and leaves x, y, z independent.  If Q, R
+// and P0 have no entries between different groups -- true for every shipped model file, whose Q
+// is Gamma diag(sigma^2) Gamma^T and whose R, P0 are diagonal (matlab/generateModel.m:9-41) --
+// P keeps exact zeros there for ever and the filter factorises into one small filter per group.
+constexpr int group_of(int type, int r) {
+  return type == UNIFORM_VELOCITY ? r % 3
+       : type == UNIFORM_ACCELERATION ? r % 3
+       : type == ANGULAR_RATES ? r % 6
+       : /* ANGULAR_VELOCITIES */ ((r % 6) < 3 ? r % 6 : 3);
+}
+
 struct ModelUV { static constexpr int TYPE = UNIFORM_VELOCITY, N = 6, K = 3, NB = 2; static constexpr bool ANGULAR = false, EKF = false; };
 struct ModelUA { static constexpr int TYPE = UNIFORM_ACCELERATION, N = 9, K = 3, NB = 3; static constexpr bool ANGULAR = false, EKF = false; };
 struct ModelAR { static constexpr int TYPE = ANGULAR_RATES, N = 18, K = 6, NB = 3; static constexpr bool ANGULAR = true, EKF = false; };
 struct ModelAV { static constexpr int TYPE = ANGULAR_VELOCITIES, N = 12, K = 6, NB = 2; static constexpr bool ANGULAR = true, EKF = true; };
+
+enum Layout : int { LAYOUT_FULL = 0, LAYOUT_PACKED = 1, LAYOUT_SEPARABLE = 2 };
 
 constexpr int model_n(int type) { return type == UNIFORM_VELOCITY ? 6 : type == UNIFORM_ACCELERATION ? 9 : type == ANGULAR_RATES ? 18 : 12; }
 constexpr int model_m(int type) { return (type == UNIFORM_VELOCITY || type == UNIFORM_ACCELERATION) ? 3 : 6; }
@@ -36,11 +52,15 @@ constexpr int model_m(int type) { return (type == UNIFORM_VELOCITY || type == UN
 // and mirrored into the registers after the load.  Offered for G = 1 (thread per target), where
 // the mirror is a register rename.  The reference's (I-KC)P is symmetric only to rounding
 // (~1e-16 relative); packed batches keep the owner-row value P[r][c], r <= c, of each pair.
-template <class M, typename T, int G_, bool PK_ = false>
+// LAYOUT_SEPARABLE: only the entries of P inside an axis group are stored (the others are
+// structurally zero); thread per target, dedicated kernel (kf_step_sep.hpp).
+template <class M, typename T, int G_, int LAYOUT_ = LAYOUT_FULL>
 struct Cfg {
   static constexpr int G = G_;
-  static constexpr bool PK = PK_;
-  static_assert(!PK_ || G_ == 1, "packed storage is implemented for the thread-per-target mapping");
+  static constexpr int LAYOUT = LAYOUT_;
+  static constexpr bool PK = LAYOUT_ == LAYOUT_PACKED;
+  static constexpr bool SEP = LAYOUT_ == LAYOUT_SEPARABLE;
+  static_assert(LAYOUT_ == LAYOUT_FULL || G_ == 1, "packed / separable storage use the thread-per-target mapping");
   static constexpr int N = M::N, K = M::K, NB = M::NB;
   static_assert(K % G == 0, "lanes per target must divide the block size");
   static constexpr int RPL = N / G;           // rows of x / P per lane
@@ -48,7 +68,13 @@ struct Cfg {
   static constexpr int TPW = 64 / G;          // targets per wavefront (= per tile)
   static constexpr int LPT = TPW * G;         // active lanes per tile
   static constexpr int UW = M::ANGULAR ? (3 + G - 1) / G : 0;  // unwrap-memory words per lane
-  static constexpr int PW = PK ? N * (N + 1) / 2 : RPL * N;    // words of P per lane in HBM
+  static constexpr int sep_count() {
+    int k = 0;
+    for (int r = 0; r < M::N; ++r)
+      for (int c = 0; c < M::N; ++c) k += group_of(M::TYPE, r) == group_of(M::TYPE, c) ? 1 : 0;
+    return k;
+  }
+  static constexpr int PW = SEP ? sep_count() : PK ? N * (N + 1) / 2 : RPL * N;   // words of P per lane in HBM
   static constexpr int RW = PW + RPL + UW;                     // record words per lane in HBM
   static constexpr int FRW = RPL * (N + 1) + UW;               // words of the full register image
   static constexpr int VW = 16 / (int)sizeof(T);               // words per 16-byte chunk
@@ -65,6 +91,22 @@ struct Cfg {
   static constexpr int UW_OFF = PW + RPL;
   // upper-triangle index of (r, c), r <= c
   static constexpr int tri(int r, int c) { return r * N - r * (r - 1) / 2 + (c - r); }
+  // word of P(r, c) in the record of the lane that owns row r (G = 1 for the non-full layouts),
+  // -1 for a structural zero of the separable layout
+  static constexpr int p_word(int r, int c) {
+    if (SEP) {
+      if (group_of(M::TYPE, r) != group_of(M::TYPE, c)) return -1;
+      int k = 0;
+      for (int rr = 0; rr < N; ++rr)
+        for (int cc = 0; cc < N; ++cc) {
+          if (rr == r && cc == c) return k;
+          k += group_of(M::TYPE, rr) == group_of(M::TYPE, cc) ? 1 : 0;
+        }
+      return -1;
+    }
+    if (PK) return r <= c ? tri(r, c) : tri(c, r);
+    return ((r % K) / G + (r / K) * KPL) * N + c;
+  }
   // LDS exchange words per target (G > 1 only)
   static constexpr int EXA = K * N;                 // top rows of P^- (AV: also the 6 mid rows)
   static constexpr int EXB = K * K;                 // S^-1
@@ -73,6 +115,15 @@ struct Cfg {
   // index is TPW, never alias a live target's scratch
   static constexpr int GS = (64 + G - 1) / G;
   static constexpr int EX_WORDS = (G == 1) ? 0 : GS * (EXA + EXB + EXC);
+  // p_word as a compile-time table (so that fully unrolled kernels index registers statically)
+  struct WordTable { int v[N][N]; };
+  static constexpr WordTable make_table() {
+    WordTable t{};
+    for (int r = 0; r < N; ++r)
+      for (int c = 0; c < N; ++c) t.v[r][c] = p_word(r, c);
+    return t;
+  }
+  static constexpr WordTable PWORD = make_table();
   static constexpr int QR_WORDS = N * N + K * K;
   // wavefronts per workgroup: as many as keep static LDS under 64 KiB
   static constexpr long LDS4 = (long)(4 * (QR_WORDS + EX_WORDS) + 1) * (long)sizeof(T);
@@ -90,7 +141,7 @@ __host__ __device__ inline long record_word_offset(int lane, int w) {
 }
 
 struct LayoutInfo {
-  int n, m, g, packed, tpw, lpt, record_words;
+  int n, m, g, layout, tpw, lpt, record_words;
   long tile_bytes, tile_payload;
 };
 

@@ -13,6 +13,7 @@ MODEL_TYPES = {"angular_rates": 0, "angular_velocities": 1, "uniform_acceleratio
 MODEL_DIMS = {0: (18, 6), 1: (12, 6), 2: (9, 3), 3: (6, 3)}
 DTYPES = {"f64": 0, "f32": 1}
 SYMMETRIC_PACKED = 100   # add to lanes_per_target=1: upper triangle of P only in HBM
+AXIS_SEPARABLE = 200     # add to lanes_per_target=1: only the per-axis blocks of P (exact for decoupled Q, R, P0)
 
 
 def _dp(a):
@@ -52,6 +53,7 @@ class Batch:
     meas_dim = property(lambda s: s._lib.target_batch_meas_dim(s._h))
     lanes_per_target = property(lambda s: s._lib.target_batch_lanes_per_target(s._h))
     symmetric_packed = property(lambda s: bool(s._lib.target_batch_is_symmetric_packed(s._h)))
+    layout = property(lambda s: ("full", "symmetric_packed", "axis_separable")[s._lib.target_batch_layout(s._h)])
     algorithmic_bytes = property(lambda s: s._lib.target_batch_algorithmic_bytes(s._h))
     resident_bytes_per_target = property(lambda s: s._lib.target_batch_resident_bytes_per_target(s._h))
 

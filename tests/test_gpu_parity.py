@@ -21,11 +21,14 @@ te = pytest.importorskip("target_estimation_amd")
 TOL = {"f64": dict(x_atol=1e-10, x_rtol=1e-10, P_rel=1e-9, out_atol=1e-9),
        "f32": dict(x_atol=2e-3, x_rtol=1e-4, P_rel=2e-3, out_atol=5e-3)}
 
-# 101 = thread per target with symmetric-packed P in HBM (1 + TARGET_LAYOUT_SYMMETRIC_PACKED)
-LANES = {"uniform_velocity": {"f64": [1, 3, 101], "f32": [1, 3, 101]},
-         "uniform_acceleration": {"f64": [1, 3, 101], "f32": [1, 3, 101]},
-         "angular_rates": {"f64": [3, 6], "f32": [2, 3, 6]},
-         "angular_velocities": {"f64": [3, 6], "f32": [1, 3, 6, 101]}}
+# 101 = thread per target with symmetric-packed P in HBM (1 + TARGET_LAYOUT_SYMMETRIC_PACKED);
+# 201 = axis-separable layout (1 + TARGET_LAYOUT_AXIS_SEPARABLE); 0 = automatic (separable here,
+# because the shipped Q, R, P0 do not couple axes)
+LANES = {"uniform_velocity": {"f64": [0, 1, 3, 101, 201], "f32": [1, 3, 101, 201]},
+         "uniform_acceleration": {"f64": [0, 1, 3, 101, 201], "f32": [1, 3, 101, 201]},
+         "angular_rates": {"f64": [0, 3, 6, 201], "f32": [2, 3, 6, 201]},
+         "angular_velocities": {"f64": [0, 3, 6, 201], "f32": [1, 3, 6, 101, 201]}}
+LAYOUT_OF = {0: "axis_separable", 101: "symmetric_packed", 201: "axis_separable"}
 CASES = [(m, d, g) for m in HARNESS_ORDER for d in ("f64", "f32") for g in LANES[m][d]]
 
 
@@ -62,8 +65,8 @@ def test_dense_batch_matches_oracle(models, name, dtype, lanes):
     assert mgr.init_batch(ids, dt, 0.0, p0, v0, a0) == N
     orc = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], p0, dt, 0.0, v0, a0, dtype=dtype)
     b = mgr.batches()[0]
-    assert b.size == N and b.lanes_per_target == lanes % 100 and b.state_dim == m["Q"].shape[0]
-    assert b.symmetric_packed == (lanes > 100)
+    assert b.size == N and b.lanes_per_target == (lanes % 100 or 1) and b.state_dim == m["Q"].shape[0]
+    assert b.layout == LAYOUT_OF.get(lanes, "full")
     np.testing.assert_array_equal(b.slot_ids(), ids)
     check_state(mgr, ids, orc, dtype, "after init")
     worst = (0.0, 0.0)
@@ -97,6 +100,73 @@ def test_dense_batch_matches_oracle(models, name, dtype, lanes):
     np.testing.assert_allclose(dp.cpu().numpy(), orc.pose(), atol=t["out_atol"])
     print("\n[parity] %s %s G=%d worst |dx| %.3e  worst dP/scale %.3e" % (name, dtype, lanes, worst[0], worst[1]))
     mgr.close()
+
+
+def coupled(m, seed=3):
+    """Q, R, P0 that couple every axis with every other one (valid covariances, same scales)."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for k in ("Q", "R", "P"):
+        A = m[k]
+        n = A.shape[0]
+        B = rng.normal(size=(n, n)) * 0.2
+        d = np.sqrt(np.diag(A))
+        out[k] = A + (B @ B.T) * np.outer(d, d)
+    return out
+
+
+@pytest.mark.parametrize("name,dtype", [(m, d) for m in HARNESS_ORDER for d in ("f64", "f32")])
+def test_general_matrices_use_the_dense_kernel(models, name, dtype):
+    """With Q, R, P0 that couple the axes the automatic layout must fall back to the dense kernel
+    (and the separable layout must be refused); parity as for the shipped models."""
+    m = models[name]
+    cm = coupled(m)
+    N, steps, dt = 150, 40, 0.004
+    p0, meas = synth_stream(name, N, steps, seed=13)
+    ids = np.arange(N, dtype=np.uint32)
+    mgr = te.TargetManager(dtype=dtype)                       # no default model: typed init
+    mgr.init_batch(ids, dt, 0.0, p0, type=m["model"], Q=cm["Q"], R=cm["R"], P0=cm["P"])
+    b = mgr.batches()[0]
+    assert b.layout == "full"
+    orc = oracle.OracleBatch(m["model"], cm["Q"], cm["R"], cm["P"], p0, dt, dtype=dtype)
+    for s in range(steps):
+        b.step(dt, to_soa(meas[s], b))
+        orc.step(dt, meas[s])
+    check_state(mgr, ids, orc, dtype, "coupled %s" % name)
+    _, P = mgr.get_state_batch(ids[:3])
+    n = P.shape[1]
+    assert np.abs(P[0][0, 1]) > 0 and np.abs(P[0][1, n - 1]) > 0     # really dense
+    mgr.close()
+    sep = te.TargetManager(dtype=dtype, lanes_per_target=201)
+    with pytest.raises(RuntimeError, match="couple different axes"):
+        sep.init_batch(ids, dt, 0.0, p0, type=m["model"], Q=cm["Q"], R=cm["R"], P0=cm["P"])
+    sep.close()
+
+
+@pytest.mark.parametrize("name", HARNESS_ORDER)
+def test_separable_layout_equals_dense_bit_for_bit(models, name):
+    """The axis-separable kernel is the dense arithmetic minus the exact-zero terms: same bits in x
+    and in every structurally non-zero entry of P, exact zeros elsewhere (f64)."""
+    m = models[name]
+    N, steps, dt = 200, 60, 0.004
+    p0, meas = synth_stream(name, N, steps, seed=17)
+    ids = np.arange(N, dtype=np.uint32)
+    res = []
+    for lanes in (201, 3 if name in ("uniform_velocity", "uniform_acceleration") else 6):
+        mgr = te.TargetManager(model_path(name), lanes_per_target=lanes)
+        mgr.init_batch(ids, dt, 0.0, p0)
+        b = mgr.batches()[0]
+        for s in range(steps):
+            b.step(dt, to_soa(meas[s], b), None if s % 7 else torch.from_numpy((np.arange(N) % 3 > 0).astype(np.uint8)).cuda())
+        res.append(mgr.get_state_batch(ids))
+        mgr.close()
+    (xs, Ps), (xd, Pd) = res
+    if name == "angular_velocities":          # the EKF Jacobian expressions may contract differently
+        np.testing.assert_allclose(xs, xd, rtol=1e-13, atol=1e-14)
+        np.testing.assert_allclose(Ps, Pd, rtol=1e-11, atol=1e-22)
+    else:
+        np.testing.assert_array_equal(xs, xd)
+        np.testing.assert_array_equal(Ps, Pd + 0.0)      # +0.0: -0 == 0
 
 
 @pytest.mark.parametrize("name", HARNESS_ORDER)
