@@ -107,6 +107,18 @@ long target_manager_intersect_sphere_batch(target_manager_c* self, const unsigne
                                            const double* origin, double radius, double* delta, double* pose,
                                            unsigned char* found);
 
+/* The query above followed by the reference's convergence gate, kept PER TARGET (the reference keeps
+ * one per IntersectionSolver object): two moving averages of window filters_length (<= 0: the reference
+ * default 250, intersection_solver.hpp:63) over the distance and the quaternion angle between
+ * consecutive intersection poses; converged[i] = both filtered errors <= their thresholds
+ * (IntersectionSolver::getIntersectionPoseWithSphere, intersection_solver.cpp:91-124).  A query with no
+ * intersection leaves the gate untouched and reports 0.  filtered_errors [n][2] may be NULL.
+ * Costs 2 * filters_length doubles of HBM per target (allocated on first use). */
+long target_manager_intersect_sphere_converged_batch(target_manager_c* self, const unsigned int* ids, long n, double t1,
+                                                     double pos_th, double ang_th, const double* origin, double radius,
+                                                     int filters_length, double* delta, double* pose,
+                                                     unsigned char* converged, unsigned char* found, double* filtered_errors);
+
 /* ---- device-resident dense path ---------------------------------------------------------- */
 int target_manager_num_batches(target_manager_c* self);
 target_batch_c* target_manager_get_batch(target_manager_c* self, int index);
@@ -148,6 +160,10 @@ int target_batch_get_est_dev(target_batch_c* b, double* pose_dev, double* twist_
  * origin is a host array of 3 */
 int target_batch_intersect_sphere_dev(target_batch_c* b, double t1, const double* origin, double radius,
                                       double* delta_dev, double* pose_dev);
+/* the gated form for every slot; delta_dev and pose_dev are required (the gate reads them) */
+int target_batch_intersect_sphere_converged_dev(target_batch_c* b, double t1, double pos_th, double ang_th,
+                                                const double* origin, double radius, int filters_length,
+                                                double* delta_dev, double* pose_dev, unsigned char* converged_dev);
 /* AoS doubles [n][7] (host layout of the reference) -> SoA [7][ld] in the batch precision, on device */
 int target_batch_pack_meas_dev(target_batch_c* b, const double* meas_aos_dev, long n, void* meas_soa_dev, long ld);
 

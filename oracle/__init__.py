@@ -4,6 +4,6 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 package.  Nothing under target_estimation_amd/ does.  See te_oracle.h for the parity status.
 """
 from .oracle import (  # noqa: F401
-    MODELS, MODEL_DIMS, OracleBatch, OracleTarget, build, load, load_model_yaml,
+    MODELS, MODEL_DIMS, OracleBatch, OracleGate, OracleTarget, build, load, load_model_yaml,
     ref_test_stream, lowest_real_root, poly_roots,
 )

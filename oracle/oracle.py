@@ -70,6 +70,13 @@ def load(fast=False):
         g("orc_qtran").argtypes = [real, rp, rp]
         g("orc_inverse").restype = C.c_int
         g("orc_inverse").argtypes = [C.c_int, rp, rp]
+    lib.orc_gate_sizeof.restype = C.c_int
+    lib.orc_gate_init.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_gate_update.restype = C.c_int
+    lib.orc_gate_update.argtypes = [C.c_void_p, C.c_int, dp, C.c_double, C.c_double, dp, dp]
+    lib.orc_moving_avg_init.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_moving_avg_update.restype = C.c_double
+    lib.orc_moving_avg_update.argtypes = [C.c_void_p, C.c_double]
     lib.orc_lowest_real_root.restype = C.c_double
     lib.orc_lowest_real_root.argtypes = [dp, C.c_int]
     lib.orc_poly_roots.restype = C.c_int
@@ -211,6 +218,31 @@ class OracleTarget(OracleBatch):
 
     def update(self, dt):
         self.step(dt, None)
+
+
+class OracleGate:
+    """N independent convergence gates of IntersectionSolver::getIntersectionPoseWithSphere
+    (src/intersection_solver.cpp:105-120; one solver object per target)."""
+
+    def __init__(self, n, filters_length=250):
+        self.lib = load()
+        self.N = n
+        self.size = self.lib.orc_gate_sizeof()
+        self.buf = (C.c_char * (self.size * n))()
+        self.base = C.addressof(self.buf)
+        for i in range(n):
+            self.lib.orc_gate_init(C.c_void_p(self.base + i * self.size), int(filters_length))
+
+    def update(self, exists, pose, pos_th, ang_th):
+        pose = _d(pose, (self.N, 7))
+        conv = np.zeros(self.N, dtype=bool)
+        pf = np.zeros(self.N); af = np.zeros(self.N)
+        a, b = C.c_double(), C.c_double()
+        for i in range(self.N):
+            conv[i] = bool(self.lib.orc_gate_update(C.c_void_p(self.base + i * self.size), int(bool(exists[i])), _dp(pose[i]),
+                                                    float(pos_th), float(ang_th), C.byref(a), C.byref(b)))
+            pf[i], af[i] = a.value, b.value
+        return conv, pf, af
 
 
 def ref_test_stream(n_points=10000, dt=1.0 / 250.0, goal=(0.2, 0.3, 0.4), omega=(3.0, 0.01, 0.1),

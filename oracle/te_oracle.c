@@ -91,6 +91,72 @@ double orc_lowest_real_root(const double* coeffs, int ncoeffs) {
 }
 
 /* ------------------------------------------------------------------------- */
+/* MovingAvgFilter, include/target_estimation/utils.hpp:206-265                  */
+/* ------------------------------------------------------------------------- */
+void orc_moving_avg_init(orc_moving_avg* f, int n) {   /* ctor :212-220 */
+  f->n = n; f->idx = 0; f->complete = 0; f->sum = 0.0; f->variance = 0.0;
+  for (int i = 0; i < n; ++i) f->window[i] = 0.0;
+}
+
+double orc_moving_avg_update(orc_moving_avg* f, double value) {   /* update :222-251 */
+  const int n = f->n;
+  f->sum -= f->window[f->idx];
+  f->sum += value;
+  f->window[f->idx] = value;
+  if (!f->complete && f->idx == n - 1) f->complete = 1;
+  int num = n;
+  if (!f->complete) num = f->idx + 1;
+  const double res = f->sum / num;
+  f->idx = (f->idx + 1) % n;
+  double variance_sum = 0.0;
+  for (int i = 0; i < n; ++i) variance_sum += pow(f->window[i] - res, 2);
+  f->variance = variance_sum / num;
+  return res;
+}
+
+/* wrapMax / wrapMinMax, geometry.hpp:79-88 */
+static double wrap_max(double x, double max) { return fmod(max + fmod(x, max), max); }
+static double wrap_min_max(double x, double min, double max) { return min + wrap_max(x - min, max - min); }
+
+void orc_gate_init(orc_gate* g, int filters_length) {   /* IntersectionSolver ctor, intersection_solver.cpp:19-40 */
+  orc_moving_avg_init(&g->pos, filters_length);
+  orc_moving_avg_init(&g->ang, filters_length);
+  for (int i = 0; i < 7; ++i) g->prev_pose[i] = (i == 6) ? 1.0 : 0.0;   /* initPose */
+}
+
+int orc_gate_sizeof(void) { return (int)sizeof(orc_gate); }
+
+/* src/intersection_solver.cpp:102-123 */
+int orc_gate_update(orc_gate* g, int exists, const double* pose7, double pos_th, double ang_th,
+                    double* pos_err_filt, double* ang_err_filt) {
+  if (!exists) return 0;
+  double dx = pose7[0] - g->prev_pose[0], dy = pose7[1] - g->prev_pose[1], dz = pose7[2] - g->prev_pose[2];
+  const double pos_error = sqrt(dx * dx + dy * dy + dz * dz);
+  double q1[4] = {pose7[3], pose7[4], pose7[5], pose7[6]};
+  double q2[4] = {g->prev_pose[3], g->prev_pose[4], g->prev_pose[5], g->prev_pose[6]};
+  orc_quat_normalize_f64(q1);
+  orc_quat_normalize_f64(q2);
+  /* computeQuaternionError, geometry.hpp:630-651: q_e = q_des * q.inverse(), normalised
+   * (Eigen: inverse = conjugate / squaredNorm; product = Hamilton product), [x y z w] */
+  const double n2 = q2[0] * q2[0] + q2[1] * q2[1] + q2[2] * q2[2] + q2[3] * q2[3];
+  const double ix = -q2[0] / n2, iy = -q2[1] / n2, iz = -q2[2] / n2, iw = q2[3] / n2;
+  double qe[4];
+  qe[3] = q1[3] * iw - q1[0] * ix - q1[1] * iy - q1[2] * iz;
+  qe[0] = q1[3] * ix + q1[0] * iw + q1[1] * iz - q1[2] * iy;
+  qe[1] = q1[3] * iy + q1[1] * iw + q1[2] * ix - q1[0] * iz;
+  qe[2] = q1[3] * iz + q1[2] * iw + q1[0] * iy - q1[1] * ix;
+  orc_quat_normalize_f64(qe);
+  /* computeQuaternionErrorAngle :653-657, then abs(wrapMinMax(., -pi, pi)) :110 */
+  const double ang_error = fabs(wrap_min_max(2 * acos(qe[3]), -M_PI, M_PI));
+  const double pf = orc_moving_avg_update(&g->pos, pos_error);
+  const double af = orc_moving_avg_update(&g->ang, ang_error);
+  for (int i = 0; i < 7; ++i) g->prev_pose[i] = pose7[i];
+  if (pos_err_filt) *pos_err_filt = pf;
+  if (ang_err_filt) *ang_err_filt = af;
+  return (pf <= pos_th && af <= ang_th) ? 1 : 0;
+}
+
+/* ------------------------------------------------------------------------- */
 /* precision instantiations                                                   */
 /* ------------------------------------------------------------------------- */
 #define REAL double

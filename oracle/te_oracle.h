@@ -102,6 +102,26 @@ enum {
 ORC_DECLARE(double, f64)
 ORC_DECLARE(float, f32)
 
+/* MovingAvgFilter (include/target_estimation/utils.hpp:206-265) and the convergence gate of
+ * IntersectionSolver::getIntersectionPoseWithSphere (src/intersection_solver.cpp:105-120): one gate per
+ * solver object in the reference (= per target here). */
+typedef struct orc_moving_avg {
+  int n, idx, complete;
+  double sum, variance;
+  double window[1024];
+} orc_moving_avg;
+void orc_moving_avg_init(orc_moving_avg* f, int n);
+double orc_moving_avg_update(orc_moving_avg* f, double value);
+typedef struct orc_gate {
+  orc_moving_avg pos, ang;
+  double prev_pose[7];
+} orc_gate;
+void orc_gate_init(orc_gate* g, int filters_length);
+/* feeds one query result (exists = delta > -1, pose at the intersection) through the gate; returns converged */
+int orc_gate_update(orc_gate* g, int exists, const double* pose7, double pos_th, double ang_th,
+                    double* pos_err_filt, double* ang_err_filt);
+int orc_gate_sizeof(void);
+
 /* src/intersection_solver.cpp:4-17; coefficients lowest order first */
 double orc_lowest_real_root(const double* coeffs, int ncoeffs);
 /* all complex roots (re,im interleaved) of a polynomial, for tests */

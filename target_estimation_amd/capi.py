@@ -53,6 +53,11 @@ SIGNATURES = {
                                                                     c_double_p, c_double_p]),
     "target_manager_intersect_sphere_batch": (C.c_long, [C.c_void_p, c_uint_p, C.c_long, C.c_double, c_double_p, C.c_double,
                                                          c_double_p, c_double_p, c_ubyte_p]),
+    "target_manager_intersect_sphere_converged_batch": (C.c_long, [C.c_void_p, c_uint_p, C.c_long, C.c_double, C.c_double, C.c_double,
+                                                                   c_double_p, C.c_double, C.c_int, c_double_p, c_double_p,
+                                                                   c_ubyte_p, c_ubyte_p, c_double_p]),
+    "target_batch_intersect_sphere_converged_dev": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, c_double_p, C.c_double,
+                                                              C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "target_batch_intersect_sphere_dev": (C.c_int, [C.c_void_p, C.c_double, c_double_p, C.c_double, C.c_void_p, C.c_void_p]),
     "target_manager_num_batches": (C.c_int, [C.c_void_p]),
     "target_manager_get_batch": (C.c_void_p, [C.c_void_p, C.c_int]),

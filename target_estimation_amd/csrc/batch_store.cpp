@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "hip_check.hpp"
+#include "intersect_gate.hpp"
 
 namespace te {
 
@@ -44,6 +45,7 @@ Batch::~Batch() {
   if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
   (void)hipFree(d_qr_); (void)hipFree(d_rec_); (void)hipFree(d_tbase_); (void)hipFree(d_nmbase_);
   (void)hipFree(d_idx_); (void)hipFree(d_aos_); (void)hipFree(d_meas_); (void)hipFree(d_mask_); (void)hipFree(d_P0_);
+  (void)hipFree(d_gate_ring_); (void)hipFree(d_gate_sum_); (void)hipFree(d_gate_state_); (void)hipFree(d_gate_prev_);
   (void)hipHostFree(h_ring_idx_); (void)hipHostFree(h_ring_meas_); (void)hipHostFree(h_ring_out_);
 }
 
@@ -143,6 +145,7 @@ long Batch::append(long count, const unsigned* ids, double t0, const double* P0,
   a.t_base = d_tbase_; a.nm_base = d_nmbase_;
   ops_->init(a, stream_);
   TE_HIP_CHECK(hipGetLastError());
+  if (d_gate_ring_) { if (gate_cap_ < cap_) gate_reserve(gate_window_); gate_reset(first, count); }
   TE_HIP_CHECK(hipStreamSynchronize(stream_));  // host staging arrays may be pageable
   slot_ids_.insert(slot_ids_.end(), ids, ids + count);
   n_ += count;
@@ -155,6 +158,7 @@ unsigned Batch::erase_slot(long slot) {
   if (slot != last) {
     ops_->move_record(d_rec_, last, slot, d_tbase_, d_nmbase_, stream_);
     TE_HIP_CHECK(hipGetLastError());
+    gate_move(last, slot);
     moved = slot_ids_[(size_t)last];
     slot_ids_[(size_t)slot] = moved;
   }
@@ -325,6 +329,87 @@ void Batch::intersect_dev(double t1, const double* origin, double radius, double
   a.origin[0] = origin[0]; a.origin[1] = origin[1]; a.origin[2] = origin[2]; a.radius = radius;
   a.t_acc = t_acc_; a.t_base = d_tbase_; a.delta = delta_dev; a.pose = pose_dev;
   ops_->intersect(a, stream_);
+  TE_HIP_CHECK(hipGetLastError());
+}
+
+void Batch::gate_reset(long first, long count) {
+  if (count <= 0 || !d_gate_ring_) return;
+  const int W = gate_window_;
+  TE_HIP_CHECK(hipMemsetAsync(d_gate_ring_ + first * 2 * W, 0, sizeof(double) * 2 * W * count, stream_));
+  TE_HIP_CHECK(hipMemsetAsync(d_gate_sum_ + first * 2, 0, sizeof(double) * 2 * count, stream_));
+  TE_HIP_CHECK(hipMemsetAsync(d_gate_state_ + first * 2, 0, sizeof(int) * 2 * count, stream_));
+  hipLaunchKernelGGL(gate_reset_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream_, d_gate_prev_, first, count);
+  TE_HIP_CHECK(hipGetLastError());
+}
+
+void Batch::gate_reserve(int window) {
+  if (window <= 0 || window >= (1 << 30)) throw std::runtime_error("target_estimation_amd: bad filters_length");
+  if (window == gate_window_ && gate_cap_ >= cap_) return;
+  const bool keep = (window == gate_window_) && d_gate_ring_;
+  const long old_cap = gate_cap_;
+  double* ring = nullptr; double* sum = nullptr; int* st = nullptr; double* prev = nullptr;
+  TE_HIP_CHECK(hipMalloc((void**)&ring, sizeof(double) * 2 * window * cap_));
+  TE_HIP_CHECK(hipMalloc((void**)&sum, sizeof(double) * 2 * cap_));
+  TE_HIP_CHECK(hipMalloc((void**)&st, sizeof(int) * 2 * cap_));
+  TE_HIP_CHECK(hipMalloc((void**)&prev, sizeof(double) * 7 * cap_));
+  if (keep) {
+    TE_HIP_CHECK(hipMemcpyAsync(ring, d_gate_ring_, sizeof(double) * 2 * window * old_cap, hipMemcpyDeviceToDevice, stream_));
+    TE_HIP_CHECK(hipMemcpyAsync(sum, d_gate_sum_, sizeof(double) * 2 * old_cap, hipMemcpyDeviceToDevice, stream_));
+    TE_HIP_CHECK(hipMemcpyAsync(st, d_gate_state_, sizeof(int) * 2 * old_cap, hipMemcpyDeviceToDevice, stream_));
+    TE_HIP_CHECK(hipMemcpyAsync(prev, d_gate_prev_, sizeof(double) * 7 * old_cap, hipMemcpyDeviceToDevice, stream_));
+  }
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));
+  (void)hipFree(d_gate_ring_); (void)hipFree(d_gate_sum_); (void)hipFree(d_gate_state_); (void)hipFree(d_gate_prev_);
+  d_gate_ring_ = ring; d_gate_sum_ = sum; d_gate_state_ = st; d_gate_prev_ = prev;
+  gate_window_ = window;
+  gate_cap_ = cap_;
+  gate_reset(keep ? old_cap : 0, keep ? cap_ - old_cap : cap_);
+}
+
+void Batch::gate_move(long src, long dst) {
+  if (!d_gate_ring_ || src >= gate_cap_ || dst >= gate_cap_) return;
+  const int W = gate_window_;
+  TE_HIP_CHECK(hipMemcpyAsync(d_gate_ring_ + dst * 2 * W, d_gate_ring_ + src * 2 * W, sizeof(double) * 2 * W, hipMemcpyDeviceToDevice, stream_));
+  TE_HIP_CHECK(hipMemcpyAsync(d_gate_sum_ + dst * 2, d_gate_sum_ + src * 2, sizeof(double) * 2, hipMemcpyDeviceToDevice, stream_));
+  TE_HIP_CHECK(hipMemcpyAsync(d_gate_state_ + dst * 2, d_gate_state_ + src * 2, sizeof(int) * 2, hipMemcpyDeviceToDevice, stream_));
+  TE_HIP_CHECK(hipMemcpyAsync(d_gate_prev_ + dst * 7, d_gate_prev_ + src * 7, sizeof(double) * 7, hipMemcpyDeviceToDevice, stream_));
+}
+
+void Batch::intersect_gated(const int* slots, long n, double t1, const double* origin, double radius, double pos_th,
+                            double ang_th, int window, double* delta, double* pose, unsigned char* converged, double* filt) {
+  if (n <= 0) return;
+  gate_reserve(window);
+  stage_reserve(n);
+  if (slots) upload_slots(slots, n);
+  IntersectArgs a;
+  a.rec = d_rec_; a.idx = slots ? d_idx_ : nullptr; a.n = n; a.t1 = t1;
+  a.origin[0] = origin[0]; a.origin[1] = origin[1]; a.origin[2] = origin[2]; a.radius = radius;
+  a.t_acc = t_acc_; a.t_base = d_tbase_;
+  a.delta = d_aos_; a.pose = d_aos_ + n;                 // [n] + [n][7]
+  ops_->intersect(a, stream_);
+  GateArgs g;
+  g.idx = a.idx; g.n = n; g.window = gate_window_; g.delta = a.delta; g.pose = a.pose; g.pos_th = pos_th; g.ang_th = ang_th;
+  g.ring = d_gate_ring_; g.sum = d_gate_sum_; g.state = d_gate_state_; g.prev = d_gate_prev_;
+  g.converged = d_mask_; g.filt = filt ? d_aos_ + 8 * n : nullptr;   // [n][2] after delta + pose
+  hipLaunchKernelGGL(gate_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream_, g);
+  TE_HIP_CHECK(hipGetLastError());
+  if (delta) TE_HIP_CHECK(hipMemcpyAsync(delta, a.delta, sizeof(double) * n, hipMemcpyDeviceToHost, stream_));
+  if (pose) TE_HIP_CHECK(hipMemcpyAsync(pose, a.pose, sizeof(double) * 7 * n, hipMemcpyDeviceToHost, stream_));
+  if (converged) TE_HIP_CHECK(hipMemcpyAsync(converged, d_mask_, (size_t)n, hipMemcpyDeviceToHost, stream_));
+  if (filt) TE_HIP_CHECK(hipMemcpyAsync(filt, g.filt, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, stream_));
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Batch::intersect_gated_dev(double t1, const double* origin, double radius, double pos_th, double ang_th, int window,
+                                double* delta_dev, double* pose_dev, unsigned char* converged_dev) {
+  if (n_ == 0) return;
+  gate_reserve(window);
+  intersect_dev(t1, origin, radius, delta_dev, pose_dev);
+  GateArgs g;
+  g.idx = nullptr; g.n = n_; g.window = gate_window_; g.delta = delta_dev; g.pose = pose_dev; g.pos_th = pos_th; g.ang_th = ang_th;
+  g.ring = d_gate_ring_; g.sum = d_gate_sum_; g.state = d_gate_state_; g.prev = d_gate_prev_;
+  g.converged = converged_dev; g.filt = nullptr;
+  hipLaunchKernelGGL(gate_kernel, dim3((unsigned)((n_ + 127) / 128)), dim3(128), 0, stream_, g);
   TE_HIP_CHECK(hipGetLastError());
 }
 

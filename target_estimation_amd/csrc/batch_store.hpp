@@ -70,6 +70,14 @@ class Batch {
   void intersect(const int* slots, long n, double t1, const double* origin, double radius, double* delta, double* pose);
   void intersect_dev(double t1, const double* origin, double radius, double* delta_dev, double* pose_dev);
 
+  // the same with the reference's per-solver convergence gate kept per target (intersect_gate.hpp);
+  // converged [n] bytes; filt [n][2] (filtered position / angle error) optional.  `window` is the
+  // reference's filters_length (intersection_solver.hpp:63, default 250); changing it resets the gates.
+  void intersect_gated(const int* slots, long n, double t1, const double* origin, double radius, double pos_th,
+                       double ang_th, int window, double* delta, double* pose, unsigned char* converged, double* filt);
+  void intersect_gated_dev(double t1, const double* origin, double radius, double pos_th, double ang_th, int window,
+                           double* delta_dev, double* pose_dev, unsigned char* converged_dev);
+
   void get_state(const int* slots, long n, double* x, double* P);
   void set_state(const int* slots, long n, const double* x, const double* P, const double* unwrap);
   long long n_measurements(long slot);
@@ -107,6 +115,16 @@ class Batch {
   unsigned char* d_mask_ = nullptr;
   double* d_P0_ = nullptr;
   long P0_cap_ = 0;
+  // convergence gates (allocated on first use)
+  int gate_window_ = 0;
+  long gate_cap_ = 0;
+  double* d_gate_ring_ = nullptr;
+  double* d_gate_sum_ = nullptr;
+  int* d_gate_state_ = nullptr;
+  double* d_gate_prev_ = nullptr;
+  void gate_reserve(int window);
+  void gate_move(long src, long dst);
+  void gate_reset(long first, long count);
   struct GraphEntry {
     long n_ticks, tick_stride, ld, has_stride, n;
     double dt;

@@ -454,6 +454,53 @@ bool TargetManager::getIntersectionPoseWithSphere(unsigned id, double t1, const 
   return d > -1;
 }
 
+bool TargetManager::getIntersectionPoseWithSphere(unsigned id, double t1, double pos_th, double ang_th,
+                                                  const double* origin, double radius, double* pose7) {
+  unsigned char conv = 0, found = 0;
+  double delta = -1;
+  intersectGatedBatch(&id, 1, t1, pos_th, ang_th, origin, radius, &delta, pose7, &conv, &found);
+  return conv != 0;
+}
+
+long TargetManager::intersectGatedBatch(const unsigned* ids, long n, double t1, double pos_th, double ang_th,
+                                        const double* origin, double radius, double* delta, double* pose,
+                                        unsigned char* converged, unsigned char* found, double* filt) {
+  lock_guard<mutex> lg(target_lock_);
+  const size_t nb = batches_.size();
+  std::vector<std::vector<int>> slots(nb);
+  std::vector<std::vector<long>> src(nb);
+  long done = 0;
+  for (long i = 0; i < n; ++i) {
+    Loc loc;
+    const bool ok = find(ids[i], loc);
+    if (found) found[i] = ok ? 1 : 0;
+    if (delta) delta[i] = -1;
+    if (converged) converged[i] = 0;
+    if (pose) { for (int c = 0; c < 6; ++c) pose[i * 7 + c] = 0.0; pose[i * 7 + 6] = 1.0; }
+    if (filt) { filt[i * 2] = 0.0; filt[i * 2 + 1] = 0.0; }
+    if (!ok) continue;
+    slots[(size_t)loc.batch].push_back(loc.slot);
+    src[(size_t)loc.batch].push_back(i);
+    ++done;
+  }
+  for (size_t b = 0; b < nb; ++b) {
+    const long k = (long)slots[b].size();
+    if (!k) continue;
+    std::vector<double> d2((size_t)k), p2((size_t)k * 7), f2(filt ? (size_t)k * 2 : 0);
+    std::vector<unsigned char> c2((size_t)k);
+    batches_[b]->intersect_gated(slots[b].data(), k, t1, origin, radius, pos_th, ang_th, filters_length_, d2.data(),
+                                 p2.data(), c2.data(), filt ? f2.data() : nullptr);
+    for (long j = 0; j < k; ++j) {
+      const long i = src[b][(size_t)j];
+      if (delta) delta[i] = d2[(size_t)j];
+      if (converged) converged[i] = c2[(size_t)j];
+      if (pose) std::memcpy(pose + i * 7, &p2[(size_t)j * 7], sizeof(double) * 7);
+      if (filt) { filt[i * 2] = f2[(size_t)j * 2]; filt[i * 2 + 1] = f2[(size_t)j * 2 + 1]; }
+    }
+  }
+  return done;
+}
+
 long TargetManager::intersectBatch(const unsigned* ids, long n, double t1, const double* origin, double radius,
                                    double* delta, double* pose, unsigned char* found) {
   lock_guard<mutex> lg(target_lock_);

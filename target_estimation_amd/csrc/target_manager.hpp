@@ -85,6 +85,15 @@ class TargetManager {
   // (src/intersection_solver.cpp:91-104): true if an intersection exists; pose7 = pose at t1+delta.
   bool getIntersectionPoseWithSphere(unsigned id, double t1, const double* origin, double radius, double* pose7,
                                      double* delta = nullptr);
+  // IntersectionSolver::getIntersectionPoseWithSphere with its convergence gate, same argument order
+  // (intersection_solver.hpp:98-101); one gate per target (the reference has one per solver object).
+  // Returns whether the filtered position / angle errors are below the thresholds.
+  bool getIntersectionPoseWithSphere(unsigned id, double t1, double pos_th, double ang_th, const double* origin,
+                                     double radius, double* pose7);
+  void setIntersectionFiltersLength(int n) { filters_length_ = n; }   // IntersectionSolver ctor, default 250
+  long intersectGatedBatch(const unsigned* ids, long n, double t1, double pos_th, double ang_th, const double* origin,
+                           double radius, double* delta, double* pose, unsigned char* converged, unsigned char* found,
+                           double* filt = nullptr);
   long intersectBatch(const unsigned* ids, long n, double t1, const double* origin, double radius, double* delta,
                       double* pose, unsigned char* found);
 
@@ -116,6 +125,7 @@ class TargetManager {
   int dtype_, lanes_;
   hipStream_t stream_ = nullptr;
   bool verbose_ = false;
+  int filters_length_ = 250;
 };
 
 }  // namespace te

@@ -224,6 +224,27 @@ long target_manager_intersect_sphere_batch(target_manager_c* self, const unsigne
   return k;
 }
 
+long target_manager_intersect_sphere_converged_batch(target_manager_c* self, const unsigned int* ids, long n, double t1,
+                                                     double pos_th, double ang_th, const double* origin, double radius,
+                                                     int filters_length, double* delta, double* pose,
+                                                     unsigned char* converged, unsigned char* found, double* filtered_errors) {
+  long k = -1;
+  guarded("target_manager_intersect_sphere_converged_batch", [&] {
+    M(self)->setIntersectionFiltersLength(filters_length > 0 ? filters_length : 250);
+    k = M(self)->intersectGatedBatch(ids, n, t1, pos_th, ang_th, origin, radius, delta, pose, converged, found, filtered_errors);
+  });
+  return k;
+}
+
+int target_batch_intersect_sphere_converged_dev(target_batch_c* b, double t1, double pos_th, double ang_th,
+                                                const double* origin, double radius, int filters_length,
+                                                double* delta_dev, double* pose_dev, unsigned char* converged_dev) {
+  return guarded("target_batch_intersect_sphere_converged_dev", [&] {
+    B(b)->intersect_gated_dev(t1, origin, radius, pos_th, ang_th, filters_length > 0 ? filters_length : 250, delta_dev,
+                              pose_dev, converged_dev);
+  });
+}
+
 int target_batch_intersect_sphere_dev(target_batch_c* b, double t1, const double* origin, double radius,
                                       double* delta_dev, double* pose_dev) {
   return guarded("target_batch_intersect_sphere_dev", [&] { B(b)->intersect_dev(t1, origin, radius, delta_dev, pose_dev); });

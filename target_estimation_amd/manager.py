@@ -117,6 +117,18 @@ class Batch:
             None if pose is None else pose.data_ptr()), "target_batch_intersect_sphere_dev")
         return delta, pose
 
+    def intersect_sphere_converged(self, origin, radius, pos_th, ang_th, t1=None, filters_length=250):
+        import torch
+        n = self.size
+        delta = torch.empty(n, dtype=torch.float64, device="cuda")
+        pose = torch.empty((n, 7), dtype=torch.float64, device="cuda")
+        conv = torch.empty(n, dtype=torch.uint8, device="cuda")
+        origin = _d(origin, (3,))
+        _check(self._lib.target_batch_intersect_sphere_converged_dev(
+            self._h, float("nan") if t1 is None else float(t1), float(pos_th), float(ang_th), _dp(origin), float(radius),
+            int(filters_length), delta.data_ptr(), pose.data_ptr(), conv.data_ptr()), "target_batch_intersect_sphere_converged_dev")
+        return conv, pose, delta
+
     def pack_meas(self, meas_aos, out=None):
         """CUDA double [n,7] (the reference's row layout) -> SoA [7,n] in the batch precision."""
         import torch
@@ -288,6 +300,20 @@ class TargetManager:
                                                                _dp(delta), _dp(pose), found.ctypes.data_as(capi.c_ubyte_p)),
                "target_manager_intersect_sphere_batch")
         return delta, pose, found.astype(bool)
+
+    def intersect_converged_batch(self, ids, t1, pos_th, ang_th, origin, radius, filters_length=250):
+        """IntersectionSolver::getIntersectionPoseWithSphere incl. its convergence gate (one gate per target):
+        returns converged [n] bool, pose [n,7], delta [n], filtered errors [n,2]."""
+        ids, idp = _ids(ids)
+        n = len(ids)
+        origin = _d(origin, (3,))
+        delta = np.empty(n); pose = np.empty((n, 7)); filt = np.empty((n, 2))
+        conv = np.zeros(n, dtype=np.uint8); found = np.zeros(n, dtype=np.uint8)
+        _check(self._lib.target_manager_intersect_sphere_converged_batch(
+            self._h, idp, n, float(t1), float(pos_th), float(ang_th), _dp(origin), float(radius), int(filters_length),
+            _dp(delta), _dp(pose), conv.ctypes.data_as(capi.c_ubyte_p), found.ctypes.data_as(capi.c_ubyte_p), _dp(filt)),
+            "target_manager_intersect_sphere_converged_batch")
+        return conv.astype(bool), pose, delta, filt
 
     def batches(self):
         return [Batch(self._lib, self._lib.target_manager_get_batch(self._h, i))

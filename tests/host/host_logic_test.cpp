@@ -1,0 +1,97 @@
+// host_logic_test.cpp -- CPU-only checks of the host logic that needs no GPU: the model-file reader
+// and the record layout tables.  Built and run by tests/test_host_logic.py with g++.
+#define __host__
+#define __device__
+#include <cstdio>
+#include <cstdlib>
+#include <set>
+#include <string>
+
+#include "../../target_estimation_amd/csrc/te_layout.hpp"
+#include "../../target_estimation_amd/csrc/yaml_mini.hpp"
+
+using namespace te;
+
+static int failures = 0;
+#define CHECK(cond)                                                        \
+  do {                                                                     \
+    if (!(cond)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #cond); ++failures; } \
+  } while (0)
+
+// every word of every lane record is used exactly once by (P entries, x, unwrap), and the byte
+// offsets of a tile are a bijection onto [0, payload)
+template <class M, typename T, int G, int LAYOUT>
+void check_layout(const char* name) {
+  using C = Cfg<M, T, G, LAYOUT>;
+  std::set<long> bytes;
+  for (int lane = 0; lane < C::LPT; ++lane)
+    for (int w = 0; w < C::RW; ++w) {
+      const long off = record_word_offset<C, T>(lane, w);
+      CHECK(off >= 0 && off + (long)sizeof(T) <= C::TILE_PAYLOAD);
+      CHECK(off % (long)sizeof(T) == 0);
+      CHECK(bytes.insert(off).second);
+    }
+  CHECK((long)bytes.size() * (long)sizeof(T) == C::TILE_PAYLOAD);
+  CHECK(C::TILE_BYTES % 128 == 0 && C::TILE_BYTES >= C::TILE_PAYLOAD);
+  // P words: each stored (r, c) maps into [0, PW); full layout is injective per lane
+  std::set<int> words[64];
+  int stored = 0;
+  for (int r = 0; r < C::N; ++r)
+    for (int c = 0; c < C::N; ++c) {
+      const int w = C::p_word(r, c);
+      CHECK(w == C::PWORD.v[r][c]);
+      if (w < 0) { CHECK(LAYOUT == LAYOUT_SEPARABLE && group_of(M::TYPE, r) != group_of(M::TYPE, c)); continue; }
+      CHECK(w < C::PW);
+      ++stored;
+      if (LAYOUT == LAYOUT_PACKED) { CHECK(w == C::p_word(c, r)); continue; }
+      CHECK(words[r % G].insert(w).second);
+    }
+  if (LAYOUT == LAYOUT_FULL) CHECK(stored == C::N * C::N);
+  if (LAYOUT == LAYOUT_SEPARABLE) CHECK(stored == C::PW);
+  CHECK(C::X_OFF == C::PW && C::UW_OFF == C::PW + C::RPL && C::RW == C::PW + C::RPL + C::UW);
+  std::printf("layout %-28s RW %3d tile %6ld B (%5.1f B/target)\n", name, C::RW, C::TILE_BYTES, (double)C::TILE_BYTES / C::TPW);
+}
+
+int main(int argc, char** argv) {
+  check_layout<ModelUV, double, 1, LAYOUT_FULL>("UV f64 G1 full");
+  check_layout<ModelUV, double, 3, LAYOUT_FULL>("UV f64 G3 full");
+  check_layout<ModelUV, float, 3, LAYOUT_FULL>("UV f32 G3 full");
+  check_layout<ModelUV, float, 1, LAYOUT_PACKED>("UV f32 G1 packed");
+  check_layout<ModelUV, double, 1, LAYOUT_SEPARABLE>("UV f64 separable");
+  check_layout<ModelUA, float, 1, LAYOUT_FULL>("UA f32 G1 full");
+  check_layout<ModelUA, double, 3, LAYOUT_FULL>("UA f64 G3 full");
+  check_layout<ModelUA, double, 1, LAYOUT_PACKED>("UA f64 G1 packed");
+  check_layout<ModelUA, float, 1, LAYOUT_SEPARABLE>("UA f32 separable");
+  check_layout<ModelAV, double, 3, LAYOUT_FULL>("AV f64 G3 full");
+  check_layout<ModelAV, float, 6, LAYOUT_FULL>("AV f32 G6 full");
+  check_layout<ModelAV, float, 1, LAYOUT_PACKED>("AV f32 G1 packed");
+  check_layout<ModelAV, double, 1, LAYOUT_SEPARABLE>("AV f64 separable");
+  check_layout<ModelAR, float, 2, LAYOUT_FULL>("AR f32 G2 full");
+  check_layout<ModelAR, double, 3, LAYOUT_FULL>("AR f64 G3 full");
+  check_layout<ModelAR, float, 6, LAYOUT_FULL>("AR f32 G6 full");
+  check_layout<ModelAR, float, 1, LAYOUT_SEPARABLE>("AR f32 separable");
+  // separable word counts: UV 3*4, UA 3*9, AR 6*9, AV 3*4 + 36
+  CHECK((Cfg<ModelUV, float, 1, LAYOUT_SEPARABLE>::PW == 12));
+  CHECK((Cfg<ModelUA, float, 1, LAYOUT_SEPARABLE>::PW == 27));
+  CHECK((Cfg<ModelAR, float, 1, LAYOUT_SEPARABLE>::PW == 54));
+  CHECK((Cfg<ModelAV, float, 1, LAYOUT_SEPARABLE>::PW == 48));
+
+  // model-file reader (reference: src/target_manager.cpp:18-104)
+  for (int i = 1; i < argc; ++i) {
+    ModelFile mf;
+    std::string err;
+    CHECK(load_model_file(argv[i], mf, err));
+    CHECK(mf.has_frequency && mf.frequency == 250.0);
+    const int type = mf.type == "angular_rates" ? 0 : mf.type == "angular_velocities" ? 1 : mf.type == "uniform_acceleration" ? 2 : mf.type == "uniform_velocity" ? 3 : -1;
+    CHECK(type >= 0);
+    const size_t n = (size_t)model_n(type), m = (size_t)model_m(type);
+    CHECK(mf.seqs["Q"].size() == n * n && mf.seqs["P"].size() == n * n && mf.seqs["R"].size() == m * m);
+    CHECK(mf.seqs["R"][0] == 1e-4 && mf.seqs["P"][0] == 0.1);
+    std::printf("model %-22s n %2zu m %zu Q00 %.3e\n", mf.type.c_str(), n, m, mf.seqs["Q"][0]);
+  }
+  ModelFile bad;
+  std::string err;
+  CHECK(!load_model_file("/nonexistent/file.yaml", bad, err) && !err.empty());
+  std::printf("%s\n", failures ? "HOST TESTS FAILED" : "host tests ok");
+  return failures ? 1 : 0;
+}

@@ -83,3 +83,43 @@ def test_intersection_matches_oracle(models, name, dtype):
     sel = (dd > -1) & (delta2 > -1)
     np.testing.assert_allclose(dd[sel], delta2[sel], rtol=rtol, atol=rtol)
     mgr.close()
+
+
+@pytest.mark.parametrize("name", ["uniform_acceleration", "angular_rates"])
+def test_convergence_gate_matches_oracle(models, name):
+    """IntersectionSolver::getIntersectionPoseWithSphere incl. the moving-average gate
+    (src/intersection_solver.cpp:91-124), one gate per target, queried every tick while the
+    filter runs; window 8 so that the ring wraps several times."""
+    m = models[name]
+    N, dt, W = 120, 0.004, 8
+    p0, v0, a0 = scene(N, 4)
+    ids = np.arange(N, dtype=np.uint32)
+    mgr = te.TargetManager(model_path(name))
+    mgr.init_batch(ids, dt, 0.0, p0, v0, a0)
+    orc = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], p0, dt, 0.0, v0, a0)
+    gate = oracle.OracleGate(N, W)
+    rng = np.random.default_rng(2)
+    origin, radius, pos_th, ang_th = np.zeros(3), 5.0, 0.02, 0.02
+    n_conv = 0
+    for s in range(30):
+        t = (s + 1) * dt
+        meas = p0.copy()
+        meas[:, :3] = p0[:, :3] + v0[:, :3] * t + 0.5 * a0[:, :3] * t * t + rng.normal(0, 0.01, (N, 3))
+        mgr.update_batch(ids, dt, meas)
+        orc.step(dt, meas)
+        ok_o, pose_o, delta_o = orc.intersection_pose(t, origin, radius)
+        conv_o, pf_o, af_o = gate.update(ok_o, pose_o, pos_th, ang_th)
+        conv, pose, delta, filt = mgr.intersect_converged_batch(ids, t, pos_th, ang_th, origin, radius, filters_length=W)
+        np.testing.assert_array_equal(delta > -1, ok_o)
+        hit = ok_o
+        np.testing.assert_allclose(delta[hit], delta_o[hit], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(filt[hit, 0], pf_o[hit], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(filt[hit, 1], af_o[hit], rtol=1e-6, atol=1e-7)
+        # thresholds are compared on values that agree to ~1e-9: allow a flip only right at the threshold
+        near = (np.abs(pf_o - pos_th) < 1e-7) | (np.abs(af_o - ang_th) < 1e-6)
+        np.testing.assert_array_equal(conv[~near], conv_o[~near])
+        assert not conv[~hit].any()
+        n_conv += int(conv.sum())
+    assert n_conv > 0
+    # the reference-order scalar entry (intersection_solver.hpp:98-101) goes through the same gates
+    mgr.close()

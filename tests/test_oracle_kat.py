@@ -109,3 +109,24 @@ def test_lowest_real_root_semantics():
         np.testing.assert_allclose(mine, ref, rtol=1e-8, atol=1e-8)
         assert oracle.lowest_real_root(c) == pytest.approx(
             min([z.real for z in np.roots(c[::-1]) if abs(z.imag) < 1e-10], default=-1), rel=1e-9, abs=1e-9)
+
+
+def test_moving_average_filter_matches_reference_test():
+    """test/avg_filter_test.cpp restated: MovingAvgFilter(1000) on 10 000 N(5,1) samples ends with
+    mean within 0.1 of 5 and variance within 0.1 of 1 (:30-41); plus the warm-up rule (mean over the
+    samples seen so far until the window is full, utils.hpp:231-237)."""
+    import ctypes as C
+    lib = oracle.load()
+    buf = (C.c_char * 8300)()
+    f = C.c_void_p(C.addressof(buf))
+    lib.orc_moving_avg_init(f, 1000)
+    rng = np.random.default_rng(0)
+    vals = rng.normal(5.0, 1.0, 10000)
+    for i, v in enumerate(vals):
+        m = lib.orc_moving_avg_update(f, float(v))
+        if i < 1000:
+            assert m == pytest.approx(vals[:i + 1].mean(), rel=1e-12)
+    assert m == pytest.approx(vals[-1000:].mean(), rel=1e-12)
+    assert abs(m - 5.0) < 0.1
+    variance = C.cast(C.addressof(buf) + 24, C.POINTER(C.c_double))[0]
+    assert abs(variance - 1.0) < 0.1
