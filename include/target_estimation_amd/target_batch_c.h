@@ -167,6 +167,26 @@ int target_batch_intersect_sphere_converged_dev(target_batch_c* b, double t1, do
 /* AoS doubles [n][7] (host layout of the reference) -> SoA [7][ld] in the batch precision, on device */
 int target_batch_pack_meas_dev(target_batch_c* b, const double* meas_aos_dev, long n, void* meas_soa_dev, long ld);
 
+/* ---- measurement ingest: the ROS node's mailbox / has-measurement / expiry policy --------------- */
+/* Transport-agnostic restatement of class Measurement (target_manager_ros.hpp:74-134) and
+ * RosTargetManager::update (src/target_manager_ros.cpp:41-92).  The caller pushes (id | frame name,
+ * stamp, pose); one tick = create the targets seen for the first time, predict+update those whose
+ * mailbox holds a new measurement, predict the others, erase those whose last measurement is older
+ * than the expiration time; as one batched init + one batched step.
+ * Q == NULL: new targets use the manager's default model (then type, R, P0 are ignored). */
+typedef void target_ingest_c;
+target_ingest_c* target_ingest_new(target_manager_c* manager, int type, const double* Q, const double* R, const double* P0);
+void target_ingest_delete(target_ingest_c* ingest);
+void target_ingest_set_expiration_time(target_ingest_c* ingest, double seconds);   /* setExpirationTime, :99-103 */
+void target_ingest_set_token_name(target_ingest_c* ingest, const char* token);      /* setTargetTokenName, :94-97 */
+int target_ingest_push(target_ingest_c* ingest, unsigned int id, double stamp, const double* pose);
+/* 1 taken, 0 frame name without the token, -1 token present but not "<name>_<id>" (the reference then
+ * drops the rest of the message, target_manager_ros.cpp:34-35) */
+int target_ingest_push_named(target_ingest_c* ingest, const char* child_frame_id, double stamp, const double* pose);
+/* one node tick at wall time `now`; ids_out / poses_out ([capacity], [capacity][7]) receive the live
+ * targets in ascending id order with their filtered poses; returns their number */
+long target_ingest_tick(target_ingest_c* ingest, double dt, double now, unsigned int* ids_out, double* poses_out, long capacity);
+
 #ifdef __cplusplus
 }
 #endif

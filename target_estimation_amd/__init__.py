@@ -2,6 +2,6 @@
 TargetManager C ABI of graiola/target_estimation.  See DESIGN.md / INTEGRATION.md."""
 from .manager import (  # noqa: F401
     ANGULAR_RATES, ANGULAR_VELOCITIES, UNIFORM_ACCELERATION, UNIFORM_VELOCITY, MODEL_DIMS, MODEL_TYPES, Batch,
-    TargetManager,
+    MeasurementIngest, TargetManager,
 )
 from ._build import build  # noqa: F401

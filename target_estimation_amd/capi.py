@@ -59,6 +59,13 @@ SIGNATURES = {
     "target_batch_intersect_sphere_converged_dev": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, c_double_p, C.c_double,
                                                               C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "target_batch_intersect_sphere_dev": (C.c_int, [C.c_void_p, C.c_double, c_double_p, C.c_double, C.c_void_p, C.c_void_p]),
+    "target_ingest_new": (C.c_void_p, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p]),
+    "target_ingest_delete": (None, [C.c_void_p]),
+    "target_ingest_set_expiration_time": (None, [C.c_void_p, C.c_double]),
+    "target_ingest_set_token_name": (None, [C.c_void_p, C.c_char_p]),
+    "target_ingest_push": (C.c_int, [C.c_void_p, C.c_uint, C.c_double, c_double_p]),
+    "target_ingest_push_named": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double, c_double_p]),
+    "target_ingest_tick": (C.c_long, [C.c_void_p, C.c_double, C.c_double, c_uint_p, c_double_p, C.c_long]),
     "target_manager_num_batches": (C.c_int, [C.c_void_p]),
     "target_manager_get_batch": (C.c_void_p, [C.c_void_p, C.c_int]),
     "target_manager_get_batch_of_type": (C.c_void_p, [C.c_void_p, C.c_int]),

@@ -7,6 +7,7 @@
 #include <string>
 
 #include "../../include/target_estimation_amd/target_batch_c.h"
+#include "measurement_ingest.hpp"
 #include "target_manager.hpp"
 
 using te::Batch;
@@ -38,6 +39,7 @@ int guarded(const char* where, F&& f) {
 
 inline TargetManager* M(const target_manager_c* self) { return (TargetManager*)self; }
 inline Batch* B(target_batch_c* b) { return (Batch*)b; }
+inline te::MeasurementIngest* I(target_ingest_c* i) { return (te::MeasurementIngest*)i; }
 }  // namespace
 
 extern "C" {
@@ -298,6 +300,43 @@ int target_batch_get_est_dev(target_batch_c* b, double* pose_dev, double* twist_
 
 int target_batch_pack_meas_dev(target_batch_c* b, const double* meas_aos_dev, long n, void* meas_soa_dev, long ld) {
   return guarded("target_batch_pack_meas_dev", [&] { B(b)->pack_meas_dev(meas_aos_dev, n, meas_soa_dev, ld); });
+}
+
+// ---------------------------------------------------------------- measurement ingest
+target_ingest_c* target_ingest_new(target_manager_c* manager, int type, const double* Q, const double* R, const double* P0) {
+  te::MeasurementIngest* ing = nullptr;
+  guarded("target_ingest_new", [&] { ing = new te::MeasurementIngest(M(manager), type, Q, R, P0); });
+  return (target_ingest_c*)ing;
+}
+
+void target_ingest_delete(target_ingest_c* ingest) { delete I(ingest); }
+
+void target_ingest_set_expiration_time(target_ingest_c* ingest, double seconds) { I(ingest)->setExpirationTime(seconds); }
+
+void target_ingest_set_token_name(target_ingest_c* ingest, const char* token) { I(ingest)->setTargetTokenName(token); }
+
+int target_ingest_push(target_ingest_c* ingest, unsigned int id, double stamp, const double* pose) {
+  return guarded("target_ingest_push", [&] { I(ingest)->push(id, stamp, pose); });
+}
+
+int target_ingest_push_named(target_ingest_c* ingest, const char* child_frame_id, double stamp, const double* pose) {
+  int r = -2;
+  guarded("target_ingest_push_named", [&] { r = I(ingest)->push_named(child_frame_id, stamp, pose); });
+  return r;
+}
+
+long target_ingest_tick(target_ingest_c* ingest, double dt, double now, unsigned int* ids_out, double* poses_out, long capacity) {
+  long n = -1;
+  guarded("target_ingest_tick", [&] {
+    std::vector<unsigned> ids;
+    std::vector<double> poses;
+    n = I(ingest)->tick(dt, now, ids, poses);
+    for (long i = 0; i < n && i < capacity; ++i) {
+      if (ids_out) ids_out[i] = ids[(size_t)i];
+      if (poses_out) for (int c = 0; c < 7; ++c) poses_out[i * 7 + c] = poses[(size_t)i * 7 + c];
+    }
+  });
+  return n;
 }
 
 }  // extern "C"

@@ -141,6 +141,43 @@ class Batch:
         return out
 
 
+class MeasurementIngest:
+    """The ROS node's mailbox / has-measurement / expiry policy (RosTargetManager::update) over a manager."""
+
+    def __init__(self, manager, type=None, Q=None, R=None, P0=None, expiration_time=None, token=None):
+        self._lib = manager._lib
+        self._mgr = manager
+        if Q is None:
+            self._h = self._lib.target_ingest_new(manager.handle, 0, None, None, None)
+        else:
+            n, m = MODEL_DIMS[int(type)]
+            self._h = self._lib.target_ingest_new(manager.handle, int(type), _dp(_d(Q, (n, n))), _dp(_d(R, (m, m))), _dp(_d(P0, (n, n))))
+        if not self._h:
+            raise RuntimeError("target_ingest_new failed: %s" % capi.last_error())
+        if expiration_time is not None:
+            self._lib.target_ingest_set_expiration_time(self._h, float(expiration_time))
+        if token is not None:
+            self._lib.target_ingest_set_token_name(self._h, token.encode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.target_ingest_delete(self._h)
+            self._h = None
+
+    def push(self, id, stamp, pose):
+        _check(self._lib.target_ingest_push(self._h, int(id), float(stamp), _dp(_d(pose, (7,)))), "target_ingest_push")
+
+    def push_named(self, frame, stamp, pose):
+        return self._lib.target_ingest_push_named(self._h, frame.encode(), float(stamp), _dp(_d(pose, (7,))))
+
+    def tick(self, dt, now, capacity=4096):
+        ids = np.zeros(capacity, dtype=np.uint32)
+        poses = np.zeros((capacity, 7))
+        n = _check(self._lib.target_ingest_tick(self._h, float(dt), float(now), ids.ctypes.data_as(capi.c_uint_p), _dp(poses),
+                                                capacity), "target_ingest_tick")
+        return ids[:n].copy(), poses[:n].copy()
+
+
 class TargetManager:
     """ctypes mirror of the reference TargetManager; dtype 'f64' (reference precision) or 'f32'."""
 
