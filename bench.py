@@ -28,7 +28,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 # 0 = automatic: the shipped models' Q, R, P0 do not couple axes, so the library picks the exact
 # axis-separable layout.  The *_full / *_packed workloads force the dense kernel (what general
 # matrices get): full P, or symmetric-packed P (101 = 1 + TARGET_LAYOUT_SYMMETRIC_PACKED).
-TUNED_LANES = {"cfg2_full": 3, "uv1m_full": 1, "ua1m_full": 1, "ar1m_full": 6, "av1m_full": 3, "uv1m_packed": 101}
+# 301 = axis-separable with symmetric-packed group blocks (1 + TARGET_LAYOUT_AXIS_SEPARABLE_PACKED): P is then
+# symmetric by construction (the automatic layout keeps the reference's rounding-level asymmetry).
+TUNED_LANES = {"cfg2_full": 3, "uv1m_full": 1, "ua1m_full": 1, "ar1m_full": 6, "av1m_full": 3, "uv1m_packed": 101,
+               "uv1m_sp": 301, "ua1m_sp": 301, "av1m_sp": 301, "ar1m_sp": 301}
 
 WORKLOADS = {
     # name: (description, model, dtype, targets per GPU, seed)
@@ -46,6 +49,10 @@ WORKLOADS = {
     "ua1m_full": ("1000000 targets, uniform-acceleration model, fp32, dense kernel with full P", "uniform_acceleration", "f32", 1_000_000, 20240013),
     "ar1m_full": ("1000000 targets, angular-rates model, fp32, dense kernel with full P", "angular_rates", "f32", 1_000_000, 20240014),
     "av1m_full": ("1000000 targets, angular-velocities model, fp32, dense kernel with full P", "angular_velocities", "f32", 1_000_000, 20240015),
+    "uv1m_sp": ("1000000 targets, uniform-velocity model, fp64, separable + symmetric-packed groups", "uniform_velocity", "f64", 1_000_000, 20240012),
+    "ua1m_sp": ("1000000 targets, uniform-acceleration model, fp32, separable + symmetric-packed groups", "uniform_acceleration", "f32", 1_000_000, 20240013),
+    "av1m_sp": ("1000000 targets, angular-velocities model, fp32, separable + symmetric-packed groups", "angular_velocities", "f32", 1_000_000, 20240015),
+    "ar1m_sp": ("1000000 targets, angular-rates model, fp32, separable + symmetric-packed groups", "angular_rates", "f32", 1_000_000, 20240014),
     "ar1m64": ("1000000 targets, angular-rates model, fp64", "angular_rates", "f64", 1_000_000, 20240016),
     "av1m64": ("1000000 targets, angular-velocities model, fp64", "angular_velocities", "f64", 1_000_000, 20240017),
 }
@@ -191,7 +198,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--lanes", type=int, default=0, help="lanes per target (0 = tuned default)")
     ap.add_argument("--targets", type=int, default=0, help="override targets per GPU")
-    ap.add_argument("--extra", default="uv1m,ua1m,av1m,ar1m,cfg2_full,uv1m_full,uv1m_packed,ar1m_full", help="comma list of extra workloads reported under 'extra' (N=1 only; '' = none)")
+    ap.add_argument("--extra", default="uv1m,ua1m,av1m,ar1m,ar1m_sp,av1m_sp,cfg2_full,uv1m_full,uv1m_packed,ar1m_full", help="comma list of extra workloads reported under 'extra' (N=1 only; '' = none)")
     ap.add_argument("--extra-steps", type=int, default=50)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--launch-mode", default="graph", choices=["python", "sequence", "graph"],

@@ -28,6 +28,8 @@ typedef void target_batch_c; /* all targets of one (model, Q, R) inside a manage
 /* lanes_per_target = 1 + this: store only the entries of P inside an axis group (exact when Q, R and
  * P0 do not couple different axes, as in every shipped model file; refused otherwise) */
 #define TARGET_LAYOUT_AXIS_SEPARABLE 200
+/* lanes_per_target = 1 + this: axis-separable with each group block stored as its upper triangle */
+#define TARGET_LAYOUT_AXIS_SEPARABLE_PACKED 300
 #define TARGET_DTYPE_F64 0
 #define TARGET_DTYPE_F32 1
 
@@ -130,7 +132,7 @@ int target_batch_state_dim(target_batch_c* b);
 int target_batch_meas_dim(target_batch_c* b);
 int target_batch_lanes_per_target(target_batch_c* b);
 int target_batch_is_symmetric_packed(target_batch_c* b);
-/* 0 full P, 1 symmetric-packed, 2 axis-separable */
+/* 0 full P, 1 symmetric-packed, 2 axis-separable, 3 axis-separable with symmetric-packed groups */
 int target_batch_layout(target_batch_c* b);
 /* bytes one predict+update cycle of one target must move ((2n + 2n^2 + 7 (+6)) * w, or
  * (2n + n(n+1) + 7 (+6)) * w for a symmetric-packed batch, (2n + 2 sum(group^2) + 7 (+6)) * w for an

@@ -63,11 +63,12 @@ long Batch::algorithmic_bytes_per_cycle() const {
   // full P: 2n + 2n^2 + 7 (+6); symmetric-packed P: 2n + n(n+1) + 7 (+6)
   long pwords = 2 * n * n;
   if (ops_->L.layout == LAYOUT_PACKED) pwords = n * (n + 1);
-  if (ops_->L.layout == LAYOUT_SEPARABLE) {
+  if (ops_->L.layout == LAYOUT_SEPARABLE || ops_->L.layout == LAYOUT_SEPARABLE_PACKED) {
     // only the entries inside an axis group exist (the others are structural zeros): read + write
     pwords = 0;
     for (int r = 0; r < n; ++r)
-      for (int c = 0; c < n; ++c) pwords += group_of(type_, r) == group_of(type_, c) ? 2 : 0;
+      for (int c = (ops_->L.layout == LAYOUT_SEPARABLE_PACKED ? r : 0); c < n; ++c)
+        pwords += group_of(type_, r) == group_of(type_, c) ? 2 : 0;
   }
   return (2 * n + pwords + 7 + (angular ? 6 : 0)) * (long)elem_size();
 }

@@ -101,7 +101,7 @@ __global__ void init_kernel(const InitArgs a) {
   const double* P0 = a.P0 + (a.per_target_P0 ? e * N * N : 0);
   for (int r = 0; r < N; ++r) {
     state_set<C, T>(a.rec, slot, r, N, x0[r]);
-    for (int c = (C::PK ? r : 0); c < N; ++c) state_set<C, T>(a.rec, slot, r, c, (T)P0[r * N + c]);
+    for (int c = ((C::PK || C::SEPPK) ? r : 0); c < N; ++c) state_set<C, T>(a.rec, slot, r, c, (T)P0[r * N + c]);
   }
   if constexpr (M::ANGULAR) {
     for (int cc = 0; cc < 3; ++cc) *unwrap_ptr<C, T>(a.rec, slot, cc) = 0;
@@ -137,7 +137,7 @@ __global__ void set_state_kernel(char* rec, const int* idx, long n, const double
   const long slot = idx ? (long)idx[e] : e;
   if (x_in) state_set<C, T>(rec, slot, r, N, (T)x_in[e * N + r]);
   if (P_in)
-    for (int c = (C::PK ? r : 0); c < N; ++c) state_set<C, T>(rec, slot, r, c, (T)P_in[(e * N + r) * N + c]);
+    for (int c = ((C::PK || C::SEPPK) ? r : 0); c < N; ++c) state_set<C, T>(rec, slot, r, c, (T)P_in[(e * N + r) * N + c]);
   if constexpr (M::ANGULAR) {
     if (uw_in && r < 3) *unwrap_ptr<C, T>(rec, slot, r) = (T)uw_in[e * 3 + r];
   }

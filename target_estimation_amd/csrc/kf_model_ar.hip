@@ -10,6 +10,7 @@ const Ops* get_ops_ar(int dtype, int g) {
       case 3: return OpsImpl<ModelAR, double, 3>::get();
       case 6: return OpsImpl<ModelAR, double, 6>::get();
       case 201: return OpsImpl<ModelAR, double, 1, LAYOUT_SEPARABLE>::get();  // axis-separable
+      case 301: return OpsImpl<ModelAR, double, 1, LAYOUT_SEPARABLE_PACKED>::get();  // + symmetric-packed groups
       default: return nullptr;
     }
   } else if (dtype == F32) {
@@ -19,6 +20,7 @@ const Ops* get_ops_ar(int dtype, int g) {
       case 3: return OpsImpl<ModelAR, float, 3>::get();
       case 6: return OpsImpl<ModelAR, float, 6>::get();
       case 201: return OpsImpl<ModelAR, float, 1, LAYOUT_SEPARABLE>::get();  // axis-separable
+      case 301: return OpsImpl<ModelAR, float, 1, LAYOUT_SEPARABLE_PACKED>::get();  // + symmetric-packed groups
       default: return nullptr;
     }
   }

@@ -10,6 +10,7 @@ const Ops* get_ops_av(int dtype, int g) {
       case 3: return OpsImpl<ModelAV, double, 3>::get();
       case 6: return OpsImpl<ModelAV, double, 6>::get();
       case 201: return OpsImpl<ModelAV, double, 1, LAYOUT_SEPARABLE>::get();  // axis-separable
+      case 301: return OpsImpl<ModelAV, double, 1, LAYOUT_SEPARABLE_PACKED>::get();  // + symmetric-packed groups
       default: return nullptr;
     }
   } else if (dtype == F32) {
@@ -20,6 +21,7 @@ const Ops* get_ops_av(int dtype, int g) {
       case 3: return OpsImpl<ModelAV, float, 3>::get();
       case 6: return OpsImpl<ModelAV, float, 6>::get();
       case 201: return OpsImpl<ModelAV, float, 1, LAYOUT_SEPARABLE>::get();  // axis-separable
+      case 301: return OpsImpl<ModelAV, float, 1, LAYOUT_SEPARABLE_PACKED>::get();  // + symmetric-packed groups
       default: return nullptr;
     }
   }

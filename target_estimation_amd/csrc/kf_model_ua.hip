@@ -11,6 +11,7 @@ const Ops* get_ops_ua(int dtype, int g) {
       case 101: return OpsImpl<ModelUA, double, 1, LAYOUT_PACKED>::get();  // symmetric-packed P
       case 3: return OpsImpl<ModelUA, double, 3>::get();
       case 201: return OpsImpl<ModelUA, double, 1, LAYOUT_SEPARABLE>::get();  // axis-separable
+      case 301: return OpsImpl<ModelUA, double, 1, LAYOUT_SEPARABLE_PACKED>::get();  // + symmetric-packed groups
       default: return nullptr;
     }
   } else if (dtype == F32) {
@@ -20,6 +21,7 @@ const Ops* get_ops_ua(int dtype, int g) {
       case 101: return OpsImpl<ModelUA, float, 1, LAYOUT_PACKED>::get();  // symmetric-packed P
       case 3: return OpsImpl<ModelUA, float, 3>::get();
       case 201: return OpsImpl<ModelUA, float, 1, LAYOUT_SEPARABLE>::get();  // axis-separable
+      case 301: return OpsImpl<ModelUA, float, 1, LAYOUT_SEPARABLE_PACKED>::get();  // + symmetric-packed groups
       default: return nullptr;
     }
   }

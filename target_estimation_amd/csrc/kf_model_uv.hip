@@ -11,6 +11,7 @@ const Ops* get_ops_uv(int dtype, int g) {
       case 101: return OpsImpl<ModelUV, double, 1, LAYOUT_PACKED>::get();  // symmetric-packed P
       case 3: return OpsImpl<ModelUV, double, 3>::get();
       case 201: return OpsImpl<ModelUV, double, 1, LAYOUT_SEPARABLE>::get();  // axis-separable
+      case 301: return OpsImpl<ModelUV, double, 1, LAYOUT_SEPARABLE_PACKED>::get();  // + symmetric-packed groups
       default: return nullptr;
     }
   } else if (dtype == F32) {
@@ -20,6 +21,7 @@ const Ops* get_ops_uv(int dtype, int g) {
       case 101: return OpsImpl<ModelUV, float, 1, LAYOUT_PACKED>::get();  // symmetric-packed P
       case 3: return OpsImpl<ModelUV, float, 3>::get();
       case 201: return OpsImpl<ModelUV, float, 1, LAYOUT_SEPARABLE>::get();  // axis-separable
+      case 301: return OpsImpl<ModelUV, float, 1, LAYOUT_SEPARABLE_PACKED>::get();  // + symmetric-packed groups
       default: return nullptr;
     }
   }

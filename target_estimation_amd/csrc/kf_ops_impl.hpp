@@ -19,12 +19,12 @@ struct OpsImpl {
     a.dt_per = p.dt_per; a.dt = p.dt; a.t_base = p.t_base; a.nm_base = p.nm_base;
     const long waves = (p.n + C::TPW - 1) / C::TPW;
     const unsigned blocks = (unsigned)((waves + C::WPB - 1) / C::WPB);
-    if constexpr (LAYOUT == LAYOUT_SEPARABLE) {
+    if constexpr (C::SEP) {
       const unsigned b4 = (unsigned)((waves + 3) / 4);
       if (p.idx)
-        hipLaunchKernelGGL((kf_step_sep_kernel<M, T, true>), dim3(b4), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, true>), dim3(b4), dim3(256), 0, s, a);
       else
-        hipLaunchKernelGGL((kf_step_sep_kernel<M, T, false>), dim3(b4), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, false>), dim3(b4), dim3(256), 0, s, a);
     } else {
       if (p.idx)
         hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, true>), dim3(blocks), dim3(C::WPB * 64), 0, s, a);

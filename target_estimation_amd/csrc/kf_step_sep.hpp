@@ -74,9 +74,10 @@ __device__ __forceinline__ void sep_linear_axis(T* x, T (&P)[NB][NB], const T (&
   }
 }
 
-template <class M, typename T, bool INDEXED>
+template <class M, typename T, int LAYOUT, bool INDEXED>
 __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
-  using C = Cfg<M, T, 1, LAYOUT_SEPARABLE>;
+  using C = Cfg<M, T, 1, LAYOUT>;
+  static_assert(C::SEP, "separable layouts only");
   constexpr int N = C::N, K = C::K, NB = C::NB, TPW = C::TPW;
   using F = Mth<T>;
 
@@ -158,7 +159,7 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
     for (int b = 0; b < LB; ++b) {
       XW_(i + STRIDE * b) = xs[b];
 #pragma unroll
-      for (int c = 0; c < LB; ++c) mem[C::PWORD.v[i + STRIDE * b][i + STRIDE * c]] = Pb[b][c];
+      for (int c = (C::SEPPK ? b : 0); c < LB; ++c) mem[C::PWORD.v[i + STRIDE * b][i + STRIDE * c]] = Pb[b][c];
     }
   }
 
@@ -306,7 +307,7 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
     for (int r = 0; r < 6; ++r) {
       XW_(GR[r]) = xr[r];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) mem[C::PWORD.v[GR[r]][GR[c]]] = Pr[r][c];
+      for (int c = (C::SEPPK ? r : 0); c < 6; ++c) mem[C::PWORD.v[GR[r]][GR[c]]] = Pr[r][c];
     }
   }
 

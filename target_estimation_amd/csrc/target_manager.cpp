@@ -98,7 +98,7 @@ int TargetManager::chooseLayout(int type, const double* Q, const double* R, cons
   constexpr int kSeparable = 201;  // 1 + TARGET_LAYOUT_AXIS_SEPARABLE
   const bool sep = is_axis_separable(type, Q, R, P0, n_P0);
   if (lanes_ == 0) return sep ? kSeparable : 0;
-  if (lanes_ == kSeparable && !sep)
+  if ((lanes_ == kSeparable || lanes_ == kSeparable + 100) && !sep)
     throw std::runtime_error("target_estimation_amd: the axis-separable layout was requested but Q, R or P0 couple different axes");
   return lanes_;
 }

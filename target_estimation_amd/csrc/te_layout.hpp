@@ -43,7 +43,7 @@ struct ModelUA { static constexpr int TYPE = UNIFORM_ACCELERATION, N = 9, K = 3,
 struct ModelAR { static constexpr int TYPE = ANGULAR_RATES, N = 18, K = 6, NB = 3; static constexpr bool ANGULAR = true, EKF = false; };
 struct ModelAV { static constexpr int TYPE = ANGULAR_VELOCITIES, N = 12, K = 6, NB = 2; static constexpr bool ANGULAR = true, EKF = true; };
 
-enum Layout : int { LAYOUT_FULL = 0, LAYOUT_PACKED = 1, LAYOUT_SEPARABLE = 2 };
+enum Layout : int { LAYOUT_FULL = 0, LAYOUT_PACKED = 1, LAYOUT_SEPARABLE = 2, LAYOUT_SEPARABLE_PACKED = 3 };
 
 constexpr int model_n(int type) { return type == UNIFORM_VELOCITY ? 6 : type == UNIFORM_ACCELERATION ? 9 : type == ANGULAR_RATES ? 18 : 12; }
 constexpr int model_m(int type) { return (type == UNIFORM_VELOCITY || type == UNIFORM_ACCELERATION) ? 3 : 6; }
@@ -59,7 +59,8 @@ struct Cfg {
   static constexpr int G = G_;
   static constexpr int LAYOUT = LAYOUT_;
   static constexpr bool PK = LAYOUT_ == LAYOUT_PACKED;
-  static constexpr bool SEP = LAYOUT_ == LAYOUT_SEPARABLE;
+  static constexpr bool SEP = LAYOUT_ == LAYOUT_SEPARABLE || LAYOUT_ == LAYOUT_SEPARABLE_PACKED;
+  static constexpr bool SEPPK = LAYOUT_ == LAYOUT_SEPARABLE_PACKED;   // group blocks stored as upper triangles
   static_assert(LAYOUT_ == LAYOUT_FULL || G_ == 1, "packed / separable storage use the thread-per-target mapping");
   static constexpr int N = M::N, K = M::K, NB = M::NB;
   static_assert(K % G == 0, "lanes per target must divide the block size");
@@ -71,7 +72,7 @@ struct Cfg {
   static constexpr int sep_count() {
     int k = 0;
     for (int r = 0; r < M::N; ++r)
-      for (int c = 0; c < M::N; ++c) k += group_of(M::TYPE, r) == group_of(M::TYPE, c) ? 1 : 0;
+      for (int c = (LAYOUT_ == LAYOUT_SEPARABLE_PACKED ? r : 0); c < M::N; ++c) k += group_of(M::TYPE, r) == group_of(M::TYPE, c) ? 1 : 0;
     return k;
   }
   static constexpr int PW = SEP ? sep_count() : PK ? N * (N + 1) / 2 : RPL * N;   // words of P per lane in HBM
@@ -96,10 +97,11 @@ struct Cfg {
   static constexpr int p_word(int r, int c) {
     if (SEP) {
       if (group_of(M::TYPE, r) != group_of(M::TYPE, c)) return -1;
+      const int r0 = (SEPPK && c < r) ? c : r, c0 = (SEPPK && c < r) ? r : c;
       int k = 0;
       for (int rr = 0; rr < N; ++rr)
-        for (int cc = 0; cc < N; ++cc) {
-          if (rr == r && cc == c) return k;
+        for (int cc = (SEPPK ? rr : 0); cc < N; ++cc) {
+          if (rr == r0 && cc == c0) return k;
           k += group_of(M::TYPE, rr) == group_of(M::TYPE, cc) ? 1 : 0;
         }
       return -1;

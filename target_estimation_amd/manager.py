@@ -53,7 +53,7 @@ class Batch:
     meas_dim = property(lambda s: s._lib.target_batch_meas_dim(s._h))
     lanes_per_target = property(lambda s: s._lib.target_batch_lanes_per_target(s._h))
     symmetric_packed = property(lambda s: bool(s._lib.target_batch_is_symmetric_packed(s._h)))
-    layout = property(lambda s: ("full", "symmetric_packed", "axis_separable")[s._lib.target_batch_layout(s._h)])
+    layout = property(lambda s: ("full", "symmetric_packed", "axis_separable", "axis_separable_packed")[s._lib.target_batch_layout(s._h)])
     algorithmic_bytes = property(lambda s: s._lib.target_batch_algorithmic_bytes(s._h))
     resident_bytes_per_target = property(lambda s: s._lib.target_batch_resident_bytes_per_target(s._h))
 

@@ -40,14 +40,15 @@ void check_layout(const char* name) {
     for (int c = 0; c < C::N; ++c) {
       const int w = C::p_word(r, c);
       CHECK(w == C::PWORD.v[r][c]);
-      if (w < 0) { CHECK(LAYOUT == LAYOUT_SEPARABLE && group_of(M::TYPE, r) != group_of(M::TYPE, c)); continue; }
+      if (w < 0) { CHECK(C::SEP && group_of(M::TYPE, r) != group_of(M::TYPE, c)); continue; }
       CHECK(w < C::PW);
       ++stored;
-      if (LAYOUT == LAYOUT_PACKED) { CHECK(w == C::p_word(c, r)); continue; }
+      if (LAYOUT == LAYOUT_PACKED || LAYOUT == LAYOUT_SEPARABLE_PACKED) { CHECK(w == C::p_word(c, r)); continue; }
       CHECK(words[r % G].insert(w).second);
     }
   if (LAYOUT == LAYOUT_FULL) CHECK(stored == C::N * C::N);
   if (LAYOUT == LAYOUT_SEPARABLE) CHECK(stored == C::PW);
+  if (LAYOUT == LAYOUT_SEPARABLE_PACKED) CHECK(stored == 2 * C::PW - C::N);
   CHECK(C::X_OFF == C::PW && C::UW_OFF == C::PW + C::RPL && C::RW == C::PW + C::RPL + C::UW);
   std::printf("layout %-28s RW %3d tile %6ld B (%5.1f B/target)\n", name, C::RW, C::TILE_BYTES, (double)C::TILE_BYTES / C::TPW);
 }
@@ -70,6 +71,10 @@ int main(int argc, char** argv) {
   check_layout<ModelAR, double, 3, LAYOUT_FULL>("AR f64 G3 full");
   check_layout<ModelAR, float, 6, LAYOUT_FULL>("AR f32 G6 full");
   check_layout<ModelAR, float, 1, LAYOUT_SEPARABLE>("AR f32 separable");
+  check_layout<ModelAR, float, 1, LAYOUT_SEPARABLE_PACKED>("AR f32 separable packed");
+  check_layout<ModelAV, double, 1, LAYOUT_SEPARABLE_PACKED>("AV f64 separable packed");
+  check_layout<ModelUV, float, 1, LAYOUT_SEPARABLE_PACKED>("UV f32 separable packed");
+  check_layout<ModelUA, double, 1, LAYOUT_SEPARABLE_PACKED>("UA f64 separable packed");
   // separable word counts: UV 3*4, UA 3*9, AR 6*9, AV 3*4 + 36
   CHECK((Cfg<ModelUV, float, 1, LAYOUT_SEPARABLE>::PW == 12));
   CHECK((Cfg<ModelUA, float, 1, LAYOUT_SEPARABLE>::PW == 27));

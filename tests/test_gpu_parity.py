@@ -24,11 +24,11 @@ TOL = {"f64": dict(x_atol=1e-10, x_rtol=1e-10, P_rel=1e-9, out_atol=1e-9),
 # 101 = thread per target with symmetric-packed P in HBM (1 + TARGET_LAYOUT_SYMMETRIC_PACKED);
 # 201 = axis-separable layout (1 + TARGET_LAYOUT_AXIS_SEPARABLE); 0 = automatic (separable here,
 # because the shipped Q, R, P0 do not couple axes)
-LANES = {"uniform_velocity": {"f64": [0, 1, 3, 101, 201], "f32": [1, 3, 101, 201]},
-         "uniform_acceleration": {"f64": [0, 1, 3, 101, 201], "f32": [1, 3, 101, 201]},
-         "angular_rates": {"f64": [0, 3, 6, 201], "f32": [2, 3, 6, 201]},
-         "angular_velocities": {"f64": [0, 3, 6, 201], "f32": [1, 3, 6, 101, 201]}}
-LAYOUT_OF = {0: "axis_separable", 101: "symmetric_packed", 201: "axis_separable"}
+LANES = {"uniform_velocity": {"f64": [0, 1, 3, 101, 201, 301], "f32": [1, 3, 101, 201, 301]},
+         "uniform_acceleration": {"f64": [0, 1, 3, 101, 201, 301], "f32": [1, 3, 101, 201, 301]},
+         "angular_rates": {"f64": [0, 3, 6, 201, 301], "f32": [2, 3, 6, 201, 301]},
+         "angular_velocities": {"f64": [0, 3, 6, 201, 301], "f32": [1, 3, 6, 101, 201, 301]}}
+LAYOUT_OF = {0: "axis_separable", 101: "symmetric_packed", 201: "axis_separable", 301: "axis_separable_packed"}
 CASES = [(m, d, g) for m in HARNESS_ORDER for d in ("f64", "f32") for g in LANES[m][d]]
 
 
