@@ -240,6 +240,19 @@ void Batch::step_indexed(const int* slots, long n, double dt, const double* meas
   TE_HIP_CHECK(hipStreamSynchronize(stream_));  // caller's host arrays may be reused after return
 }
 
+void Batch::step_dense_host(double dt, const double* meas_aos, const unsigned char* has) {
+  if (n_ == 0) return;
+  stage_reserve(n_);
+  if (meas_aos) {
+    TE_HIP_CHECK(hipMemcpyAsync(d_aos_, meas_aos, sizeof(double) * 7 * n_, hipMemcpyHostToDevice, stream_));
+    ops_->pack_meas(d_aos_, n_, d_meas_, n_, stream_);
+  }
+  if (has) TE_HIP_CHECK(hipMemcpyAsync(d_mask_, has, (size_t)n_, hipMemcpyHostToDevice, stream_));
+  step_dense(dt, meas_aos ? d_meas_ : nullptr, n_, (meas_aos && has) ? d_mask_ : nullptr);
+  TE_HIP_CHECK(hipGetLastError());
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));  // caller's host arrays may be reused after return
+}
+
 void Batch::step_one(long slot, double dt, const double* meas7) {
   // one-target call of the reference C ABI: inputs go through a pinned, device-visible ring so
   // the launch is asynchronous and needs no staging copy

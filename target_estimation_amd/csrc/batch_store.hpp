@@ -55,6 +55,8 @@ class Batch {
   // One tick over the listed slots, host inputs (meas rows follow the order of `slots`).
   void step_indexed(const int* slots, long n, double dt, const double* meas_aos, const unsigned char* has);
   void step_one(long slot, double dt, const double* meas7);
+  // One tick over every slot in slot order, host inputs (rows of meas_aos / has follow the slot order)
+  void step_dense_host(double dt, const double* meas_aos, const unsigned char* has);
 
   // Derived outputs to host arrays; slots == null means all slots in order.
   void outputs(const int* slots, long n, double* pose, double* twist, double* acc, bool at_time, double t1);

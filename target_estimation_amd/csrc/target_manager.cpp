@@ -343,6 +343,15 @@ long long TargetManager::getNumberMeasurements(unsigned id) {
 long TargetManager::updateBatch(const unsigned* ids, long n, double dt, const double* meas, const unsigned char* has_meas) {
   lock_guard<mutex> lg(target_lock_);
   const size_t nb = batches_.size();
+  // fast path: the caller passes exactly one batch's ids in slot order (the usual case when the same
+  // id array is reused every tick): no per-id lookup, dense kernel
+  for (size_t b = 0; b < nb; ++b) {
+    Batch* bt = batches_[b].get();
+    if (bt->size() == n && n > 0 && std::memcmp(ids, bt->slot_ids().data(), sizeof(unsigned) * (size_t)n) == 0) {
+      bt->step_dense_host(dt, meas, has_meas);
+      return n;
+    }
+  }
   std::vector<std::vector<int>> slots(nb);
   std::vector<std::vector<long>> src(nb);
   long done = 0;
@@ -383,6 +392,14 @@ long TargetManager::getPoseBatch(const unsigned* ids, long n, double* pose, doub
                                  unsigned char* found, bool at_time, double t1) {
   lock_guard<mutex> lg(target_lock_);
   const size_t nb = batches_.size();
+  for (size_t b = 0; b < nb; ++b) {   // same fast path as updateBatch
+    Batch* bt = batches_[b].get();
+    if (bt->size() == n && n > 0 && std::memcmp(ids, bt->slot_ids().data(), sizeof(unsigned) * (size_t)n) == 0) {
+      bt->outputs(nullptr, n, pose, twist, acc, at_time, t1);
+      if (found) std::memset(found, 1, (size_t)n);
+      return n;
+    }
+  }
   std::vector<std::vector<int>> slots(nb);
   std::vector<std::vector<long>> src(nb);
   long done = 0;

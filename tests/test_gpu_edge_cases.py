@@ -167,7 +167,7 @@ def test_reference_harness_in_fp32(models, harness_stream, name):
     mgr.close()
 
 
-@pytest.mark.parametrize("wl", ["ar1m", "uv1m"])
+@pytest.mark.parametrize("wl", ["ar1m", "uv1m", "ar1m_full", "av1m_sp"])
 def test_full_size_properties(models, wl):
     """BASELINE-size batches (10^6 targets): properties that do not need the oracle on every target
     (finite, covariance symmetric to rounding with positive diagonal, slot ids in order, predict-only
@@ -179,7 +179,7 @@ def test_full_size_properties(models, wl):
     dt, ticks = 0.004, 6
     st = make_stream(te.MODEL_TYPES[name], N, ticks, dt, seed)
     ids = np.arange(N, dtype=np.uint32)
-    mgr = te.TargetManager(model_path(name), dtype=dtype, lanes_per_target=bench.TUNED_LANES[wl])
+    mgr = te.TargetManager(model_path(name), dtype=dtype, lanes_per_target=bench.TUNED_LANES.get(wl, 0))
     p0 = st["p0"].cpu().numpy()
     assert mgr.init_batch(ids, dt, 0.0, p0) == N
     b = mgr.batches()[0]
