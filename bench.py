@@ -96,7 +96,10 @@ def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None,
             blk = min(count, ticks - off)
             # only whole blocks are replayed from the recorded graph (one graph, recorded during
             # warm-up); partial blocks are enqueued launch by launch
-            b.step_sequence(dt, meas[off:off + blk], use_graph=(launch_mode == "graph" and off == 0 and blk == ticks))
+            if launch_mode == "fused":   # temporally fused: the whole block in ONE launch ("effective" metric)
+                b.step_fused(dt, meas[off:off + blk])
+            else:
+                b.step_sequence(dt, meas[off:off + blk], use_graph=(launch_mode == "graph" and off == 0 and blk == ticks))
             done[0] += blk
             count -= blk
 
@@ -201,7 +204,7 @@ def main():
     ap.add_argument("--extra", default="uv1m,ua1m,av1m,ar1m,ar1m_sp,av1m_sp,cfg2_full,uv1m_full,uv1m_packed,ar1m_full", help="comma list of extra workloads reported under 'extra' (N=1 only; '' = none)")
     ap.add_argument("--extra-steps", type=int, default=50)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--launch-mode", default="graph", choices=["python", "sequence", "graph"],
+    ap.add_argument("--launch-mode", default="graph", choices=["python", "sequence", "graph", "fused"],
                     help="how the per-tick launches are enqueued (always one kernel launch per tick)")
     args = ap.parse_args()
 

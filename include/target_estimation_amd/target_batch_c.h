@@ -154,6 +154,11 @@ int target_batch_step(target_batch_c* b, double dt, const void* meas_dev, long l
  * use_graph == 2 records the graph and launches nothing (set-up before a timed region). */
 int target_batch_step_sequence(target_batch_c* b, long n_ticks, double dt, const void* meas_dev, long tick_stride, long ld,
                                const unsigned char* has_meas_dev, long has_stride, int use_graph);
+/* The same n_ticks ticks in ONE launch: each target's state stays in registers across the ticks and
+ * only the measurements are read per tick (temporal fusion; identical results).  For replaying
+ * recorded streams; its throughput is an "effective" figure, not comparable with one launch per tick. */
+int target_batch_step_fused(target_batch_c* b, long n_ticks, double dt, const void* meas_dev, long tick_stride, long ld,
+                            const unsigned char* has_meas_dev, long has_stride);
 /* derived outputs of every slot into device arrays of doubles ([size][7], [size][6], [size][6];
  * any may be NULL); at_time != 0 extrapolates to t1 */
 int target_batch_get_est_dev(target_batch_c* b, double* pose_dev, double* twist_dev, double* acc_dev, int at_time, double t1);

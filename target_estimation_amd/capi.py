@@ -82,6 +82,7 @@ SIGNATURES = {
     "target_batch_slot_ids": (C.c_long, [C.c_void_p, c_uint_p, C.c_long]),
     "target_batch_step": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_long, C.c_void_p]),
     "target_batch_step_sequence": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_int]),
+    "target_batch_step_fused": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long]),
     "target_batch_get_est_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double]),
     "target_batch_pack_meas_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_long]),
 }

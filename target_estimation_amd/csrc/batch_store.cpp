@@ -222,6 +222,19 @@ void Batch::step_sequence(long n_ticks, double dt, const void* meas_base, long t
   if (meas_base && !has_base) nm_acc_ += n_ticks;
 }
 
+void Batch::step_fused(long n_ticks, double dt, const void* meas_base, long tick_stride, long ld,
+                       const unsigned char* has_base, long has_stride) {
+  if (n_ == 0 || n_ticks <= 0) return;
+  StepParams p;
+  p.rec = d_rec_; p.qr = d_qr_; p.n = n_; p.idx = nullptr; p.meas = meas_base; p.meas_ld = ld;
+  p.has_meas = has_base; p.dt_per = nullptr; p.dt = dt; p.t_base = d_tbase_; p.nm_base = d_nmbase_;
+  p.n_ticks = (int)n_ticks; p.tick_stride = tick_stride; p.has_stride = has_stride;
+  ops_->step(p, stream_);
+  TE_HIP_CHECK(hipGetLastError());
+  t_acc_ += dt * (double)n_ticks;
+  if (meas_base && !has_base) nm_acc_ += n_ticks;
+}
+
 void Batch::step_indexed(const int* slots, long n, double dt, const double* meas_aos, const unsigned char* has) {
   if (n <= 0) return;
   stage_reserve(n);

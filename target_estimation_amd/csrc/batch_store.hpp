@@ -52,6 +52,11 @@ class Batch {
   // per-launch host cost when a recorded stream is replayed; 2: record only, launch nothing).
   void step_sequence(long n_ticks, double dt, const void* meas_base, long tick_stride, long ld,
                      const unsigned char* has_base, long has_stride, int use_graph);
+  // n_ticks ticks in ONE launch: every target's state stays in registers across the ticks and only
+  // the measurements are read per tick.  Same results as n_ticks single ticks; a different
+  // ("effective", temporally fused) cost model -- for replaying recorded streams.
+  void step_fused(long n_ticks, double dt, const void* meas_base, long tick_stride, long ld,
+                  const unsigned char* has_base, long has_stride);
   // One tick over the listed slots, host inputs (meas rows follow the order of `slots`).
   void step_indexed(const int* slots, long n, double dt, const double* meas_aos, const unsigned char* has);
   void step_one(long slot, double dt, const double* meas7);

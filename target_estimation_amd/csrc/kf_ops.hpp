@@ -21,6 +21,9 @@ struct StepParams {
   double dt;
   double* t_base;
   int* nm_base;
+  int n_ticks = 1;        // > 1: temporally fused launch (state stays in registers for n_ticks ticks)
+  long tick_stride = 0;   // elements between the measurement blocks of consecutive ticks
+  long has_stride = 0;
 };
 
 struct Ops {

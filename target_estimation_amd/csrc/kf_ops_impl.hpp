@@ -5,6 +5,8 @@
 #include "kf_step.hpp"
 #include "kf_step_sep.hpp"
 
+#include <stdexcept>
+
 namespace te {
 
 template <class M, typename T, int G, int LAYOUT = LAYOUT_FULL>
@@ -17,16 +19,22 @@ struct OpsImpl {
     a.rec = p.rec; a.qr = static_cast<const T*>(p.qr); a.n = p.n; a.idx = p.idx;
     a.meas = static_cast<const T*>(p.meas); a.meas_ld = p.meas_ld; a.has_meas = p.has_meas;
     a.dt_per = p.dt_per; a.dt = p.dt; a.t_base = p.t_base; a.nm_base = p.nm_base;
+    a.n_ticks = p.n_ticks; a.tick_stride = p.tick_stride; a.has_stride = p.has_stride;
     const long waves = (p.n + C::TPW - 1) / C::TPW;
     const unsigned blocks = (unsigned)((waves + C::WPB - 1) / C::WPB);
+    if (p.n_ticks > 1 && p.idx) throw std::runtime_error("target_estimation_amd: fused multi-tick launches are dense only");
     if constexpr (C::SEP) {
       const unsigned b4 = (unsigned)((waves + 3) / 4);
-      if (p.idx)
+      if (p.n_ticks > 1)
+        hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, false, true>), dim3(b4), dim3(256), 0, s, a);
+      else if (p.idx)
         hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, true>), dim3(b4), dim3(256), 0, s, a);
       else
         hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, false>), dim3(b4), dim3(256), 0, s, a);
     } else {
-      if (p.idx)
+      if (p.n_ticks > 1)
+        hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, false, true>), dim3(blocks), dim3(C::WPB * 64), 0, s, a);
+      else if (p.idx)
         hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, true>), dim3(blocks), dim3(C::WPB * 64), 0, s, a);
       else
         hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, false>), dim3(blocks), dim3(C::WPB * 64), 0, s, a);

@@ -41,6 +41,11 @@ struct StepArgs {
   double dt;
   double* t_base;            // per-slot time offset       (touched by the indexed path only)
   int* nm_base;              // per-slot measurement count (touched when a mask is given or indexed)
+  // temporal fusion: n_ticks > 1 runs that many consecutive ticks in ONE launch with the state
+  // kept in registers; tick s reads meas + s * tick_stride and has_meas + s * has_stride
+  int n_ticks;
+  long tick_stride;
+  long has_stride;
 };
 
 template <typename T> struct Vec16;
@@ -90,7 +95,7 @@ __device__ __forceinline__ void store_record(char* tb, int lane, const T* rec) {
 
 template <typename T> __device__ __forceinline__ T sel3(int c, T a, T b, T d) { return c == 0 ? a : (c == 1 ? b : d); }
 
-template <class M, typename T, int G, int LAYOUT, bool INDEXED>
+template <class M, typename T, int G, int LAYOUT, bool INDEXED, bool FUSED = false>
 __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kernel(const StepArgs<T> a) {
   using C = Cfg<M, T, G, LAYOUT>;
   constexpr bool PK = C::PK;
@@ -167,7 +172,13 @@ __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kern
     if (a.dt_per && valid) dtd = a.dt_per[entry];
   }
   const T dt = (T)dtd;
-  const bool has = valid && a.meas != nullptr && (a.has_meas == nullptr || a.has_meas[entry] != 0);
+  int n_has = 0;
+  const int n_ticks = FUSED ? a.n_ticks : 1;   // the single-tick kernels are compiled without the loop
+  for (int tick = 0; tick < n_ticks; ++tick) {
+  const T* meas_t = a.meas ? a.meas + (long)tick * a.tick_stride : nullptr;
+  const unsigned char* has_t = a.has_meas ? a.has_meas + (long)tick * a.has_stride : nullptr;
+  const bool has = valid && meas_t != nullptr && (has_t == nullptr || has_t[entry] != 0);
+  n_has += has ? 1 : 0;
 
   // ------------------------------------------------------------------ measurement conversion
   // angular models: quaternion -> normalise -> rpy (every lane of the group redundantly)
@@ -175,10 +186,10 @@ __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kern
   if constexpr (M::ANGULAR) {
     if (has) {
       T q[4];
-      q[0] = a.meas[3 * a.meas_ld + entry];
-      q[1] = a.meas[4 * a.meas_ld + entry];
-      q[2] = a.meas[5 * a.meas_ld + entry];
-      q[3] = a.meas[6 * a.meas_ld + entry];
+      q[0] = meas_t[3 * a.meas_ld + entry];
+      q[1] = meas_t[4 * a.meas_ld + entry];
+      q[2] = meas_t[5 * a.meas_ld + entry];
+      q[3] = meas_t[6 * a.meas_ld + entry];
       quat_normalize(q);
       quat_to_rpy(q, mrpy);
     }
@@ -422,7 +433,7 @@ __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kern
         const int r = i + G * qq;
         T y;
         if (!M::ANGULAR || r < 3) {
-          y = a.meas[(long)r * a.meas_ld + entry];
+          y = meas_t[(long)r * a.meas_ld + entry];
         } else {
           const int cc = r - 3;
           const int us = cc / G;
@@ -490,6 +501,14 @@ __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kern
     }
   }
 
+  if constexpr (FUSED && PK) {
+    // a packed batch re-symmetrises P every tick (store upper triangle, reload mirrored)
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+      for (int c = r + 1; c < N; ++c) rec[c * N + r] = rec[r * N + c];
+  }
+  }  // tick loop
   if (valid) {
     if constexpr (PK) {
 #pragma unroll
@@ -506,10 +525,10 @@ __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kern
     if (i == 0) {
       if constexpr (INDEXED) {
         const long slot = a.idx[entry];
-        a.t_base[slot] += dtd;
-        if (has) a.nm_base[slot] += 1;
+        a.t_base[slot] += dtd * n_ticks;
+        a.nm_base[slot] += n_has;
       } else {
-        if (a.has_meas != nullptr && has) a.nm_base[entry] += 1;
+        if (a.has_meas != nullptr) a.nm_base[entry] += n_has;
       }
     }
   }

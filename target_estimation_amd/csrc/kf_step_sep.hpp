@@ -74,7 +74,7 @@ __device__ __forceinline__ void sep_linear_axis(T* x, T (&P)[NB][NB], const T (&
   }
 }
 
-template <class M, typename T, int LAYOUT, bool INDEXED>
+template <class M, typename T, int LAYOUT, bool INDEXED, bool FUSED = false>
 __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
   using C = Cfg<M, T, 1, LAYOUT>;
   static_assert(C::SEP, "separable layouts only");
@@ -109,18 +109,24 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
     if (a.dt_per && valid) dtd = a.dt_per[entry];
   }
   const T dt = (T)dtd;
-  const bool has = valid && a.meas != nullptr && (a.has_meas == nullptr || a.has_meas[entry] != 0);
   const T* Qm = a.qr;
   const T* Rm = a.qr + N * N;
+  int n_has = 0;
+  const int n_ticks = FUSED ? a.n_ticks : 1;
+  for (int tick = 0; tick < n_ticks; ++tick) {
+  const T* meas_t = a.meas ? a.meas + (long)tick * a.tick_stride : nullptr;
+  const unsigned char* has_t = a.has_meas ? a.has_meas + (long)tick * a.has_stride : nullptr;
+  const bool has = valid && meas_t != nullptr && (has_t == nullptr || has_t[entry] != 0);
+  n_has += has ? 1 : 0;
 
   T mrpy[3] = {0, 0, 0};
   if constexpr (M::ANGULAR) {
     if (has) {
       T q[4];
-      q[0] = a.meas[3 * a.meas_ld + entry];
-      q[1] = a.meas[4 * a.meas_ld + entry];
-      q[2] = a.meas[5 * a.meas_ld + entry];
-      q[3] = a.meas[6 * a.meas_ld + entry];
+      q[0] = meas_t[3 * a.meas_ld + entry];
+      q[1] = meas_t[4 * a.meas_ld + entry];
+      q[2] = meas_t[5 * a.meas_ld + entry];
+      q[3] = meas_t[6 * a.meas_ld + entry];
       quat_normalize(q);
       quat_to_rpy(q, mrpy);
     }
@@ -148,7 +154,7 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
     T y = 0;
     if (has) {
       if (!M::ANGULAR || i < 3) {
-        y = a.meas[(long)i * a.meas_ld + entry];
+        y = meas_t[(long)i * a.meas_ld + entry];
       } else {
         y = unwrap_angle(UWW_(i - 3), mrpy[i - 3]);   // angular_rates.cpp:85-88
         UWW_(i - 3) = y;
@@ -311,14 +317,15 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
     }
   }
 
+  }  // tick loop
   if (valid) {
     store_record<C, T>(tb, lt, mem);
     if constexpr (INDEXED) {
       const long slot = a.idx[entry];
-      a.t_base[slot] += dtd;
-      if (has) a.nm_base[slot] += 1;
+      a.t_base[slot] += dtd * n_ticks;
+      a.nm_base[slot] += n_has;
     } else {
-      if (a.has_meas != nullptr && has) a.nm_base[entry] += 1;
+      if (a.has_meas != nullptr) a.nm_base[entry] += n_has;
     }
   }
 #undef XW_

@@ -294,6 +294,13 @@ int target_batch_step_sequence(target_batch_c* b, long n_ticks, double dt, const
   });
 }
 
+int target_batch_step_fused(target_batch_c* b, long n_ticks, double dt, const void* meas_dev, long tick_stride, long ld,
+                            const unsigned char* has_meas_dev, long has_stride) {
+  return guarded("target_batch_step_fused", [&] {
+    B(b)->step_fused(n_ticks, dt, meas_dev, tick_stride, ld, has_meas_dev, has_stride);
+  });
+}
+
 int target_batch_get_est_dev(target_batch_c* b, double* pose_dev, double* twist_dev, double* acc_dev, int at_time, double t1) {
   return guarded("target_batch_get_est_dev", [&] { B(b)->outputs_dev(pose_dev, twist_dev, acc_dev, at_time != 0, t1); });
 }

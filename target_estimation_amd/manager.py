@@ -93,6 +93,17 @@ class Batch:
                                                      meas.stride(1), hp, hs, int(use_graph)),
                "target_batch_step_sequence")
 
+    def step_fused(self, dt, meas, has_meas=None):
+        """meas: CUDA tensor [ticks, 7, ld]: all ticks in ONE launch (state stays in registers)."""
+        assert meas.is_cuda and meas.dim() == 3 and meas.shape[1] == 7 and (meas.shape[2] == 1 or meas.stride(2) == 1)
+        assert meas.dtype == self.torch_dtype() and meas.shape[2] >= self.size
+        hp, hs = None, 0
+        if has_meas is not None:
+            assert has_meas.is_cuda and has_meas.dim() == 2 and has_meas.element_size() == 1
+            hp, hs = has_meas.data_ptr(), has_meas.stride(0)
+        _check(self._lib.target_batch_step_fused(self._h, meas.shape[0], float(dt), meas.data_ptr(), meas.stride(0),
+                                                  meas.stride(1), hp, hs), "target_batch_step_fused")
+
     def get_est(self, pose=True, twist=True, acc=True, t1=None):
         """Derived outputs of every slot as CUDA double tensors ([size,7], [size,6], [size,6])."""
         import torch

@@ -131,6 +131,39 @@ def test_sequence_and_graph_equal_single_steps(models, name, dtype):
         np.testing.assert_array_equal(P, out[0][1])
 
 
+@pytest.mark.parametrize("name,dtype,lanes", [("uniform_velocity", "f64", 0), ("angular_velocities", "f32", 0),
+                                              ("angular_rates", "f64", 6), ("uniform_acceleration", "f32", 101),
+                                              ("angular_rates", "f32", 301)])
+def test_temporally_fused_launch_equals_single_ticks(models, name, dtype, lanes):
+    """target_batch_step_fused (n ticks in one launch, state in registers) == n single ticks, bit for
+    bit, including a per-tick has_meas mask, the measurement counter and the clock."""
+    N, ticks, dt = 700, 12, 0.004
+    p0, meas = synth_stream(name, N, ticks, seed=18)
+    ids = np.arange(N, dtype=np.uint32)
+    mask = (np.random.default_rng(5).random((ticks, N)) < 0.8).astype(np.uint8)
+    out = []
+    for mode in ("single", "fused"):
+        mgr = te.TargetManager(model_path(name), dtype=dtype, lanes_per_target=lanes)
+        mgr.init_batch(ids, dt, 0.0, p0)
+        b = mgr.batches()[0]
+        soa = torch.from_numpy(np.ascontiguousarray(meas.transpose(0, 2, 1))).cuda().to(b.torch_dtype()).contiguous()
+        hm = torch.from_numpy(mask).cuda()
+        if mode == "single":
+            for s in range(ticks):
+                b.step(dt, soa[s], hm[s])
+            for s in range(ticks):
+                b.step(dt, soa[s])
+        else:
+            b.step_fused(dt, soa, hm)
+            b.step_fused(dt, soa)
+        out.append(mgr.get_state_batch(ids))
+        assert mgr.getNumberMeasurements(5) == int(mask[:, 5].sum()) + ticks
+        assert mgr.getTime(5) == pytest.approx(2 * ticks * dt)
+        mgr.close()
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+
+
 @pytest.mark.parametrize("name", HARNESS_ORDER)
 def test_reference_harness_in_fp32(models, harness_stream, name):
     """The reference integration test's stream through the fp32 dense path: the reference's own
