@@ -189,8 +189,16 @@ def cpu_baseline(name, targets=None, budget_s=6.0):
         if time.perf_counter() - t0 > budget_s and ticks >= 5:
             break
     el = time.perf_counter() - t0
+    # one-thread figure on a shorter sample (SURVEY 8d asks for both)
+    t1 = time.perf_counter()
+    ticks1 = 0
+    while time.perf_counter() - t1 < 1.5 or ticks1 < 2:
+        ob.step(dt, meas, nthreads=1)
+        ticks1 += 1
+    el1 = time.perf_counter() - t1
     return dict(value=n_cpu * ticks / el, unit="cycles/s", cores=int(threads), kind="port",
-                sample="%d %s targets x %d ticks (%s, OpenMP static over targets, %.1f s)" % (n_cpu, model, ticks, dtype, el))
+                sample="%d %s targets x %d ticks (%s, OpenMP static over targets, %.1f s)" % (n_cpu, model, ticks, dtype, el),
+                value_1thread=n_cpu * ticks1 / el1)
 
 
 def main():

@@ -22,6 +22,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_libraries():
+    """The HIP library and the oracle are built in-tree (and travel with the snapshot); build them on
+    demand if a checkout arrives without them (hipcc / gcc are in the image)."""
+    from target_estimation_amd import _build
+    if not os.path.exists(_build.LIB):
+        _build.build()
+    import oracle
+    oracle.build()
+
+
 def model_path(name):
     return os.path.join(ROOT, "models", MODEL_FILES[name])
 
