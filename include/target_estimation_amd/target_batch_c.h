@@ -50,6 +50,11 @@ target_manager_c* target_manager_new_ex(const char* file, int dtype, int lanes_p
 /* all launches of this manager go to `hip_stream` (a hipStream_t; NULL = default stream) */
 int target_manager_set_stream(target_manager_c* self, void* hip_stream);
 int target_manager_synchronize(target_manager_c* self);
+/* rt_logger-equivalent snapshots: with a directory set (here or by env TARGET_ESTIMATION_LOG_DIR) every
+ * target_manager_log() appends one row per target to <dir>/time_<id>, est_pose_<id>, est_twist_<id>,
+ * est_acc_<id>, cov_diag_<id> (text format of the reference's writeTxtFile, utils.hpp:96-120).  NULL or
+ * "" switches it off (log() is then a no-op, as the reference without LOGGER_ON). */
+int target_manager_set_log_directory(target_manager_c* self, const char* dir);
 const char* target_manager_last_error(void);
 
 /* TargetManager::init(type,id,dt0,t0,Q,R,P0,p0,v0,a0), target_manager.hpp:85-87.

@@ -30,6 +30,7 @@ SIGNATURES = {
     "target_manager_new_ex": (C.c_void_p, [C.c_char_p, C.c_int, C.c_int]),
     "target_manager_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "target_manager_synchronize": (C.c_int, [C.c_void_p]),
+    "target_manager_set_log_directory": (C.c_int, [C.c_void_p, C.c_char_p]),
     "target_manager_last_error": (C.c_char_p, []),
     "target_manager_init_typed": (C.c_int, [C.c_void_p, C.c_int, C.c_uint, C.c_double, C.c_double, c_double_p,
                                             c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),

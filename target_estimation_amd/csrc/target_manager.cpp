@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <iostream>
 
 #include "hip_check.hpp"
@@ -19,6 +20,8 @@ static const double kZero6[6] = {0, 0, 0, 0, 0, 0};
 TargetManager::TargetManager(int dtype, int lanes_per_target) : dtype_(dtype), lanes_(lanes_per_target) {
   const char* v = std::getenv("TARGET_ESTIMATION_VERBOSE");
   verbose_ = v && v[0] && v[0] != '0';
+  const char* ld = std::getenv("TARGET_ESTIMATION_LOG_DIR");
+  if (ld && ld[0]) log_dir_ = ld;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
     throw std::runtime_error("target_estimation_amd: no HIP device available; this library has no CPU path");
@@ -117,7 +120,35 @@ bool TargetManager::find(unsigned id, Loc& loc) {
   return true;
 }
 
-void TargetManager::log() {}
+void TargetManager::log() {
+  if (log_dir_.empty()) return;
+  lock_guard<mutex> lg(target_lock_);
+  for (auto& b : batches_) {
+    const long n = b->size();
+    if (!n) continue;
+    const int N = b->n_state();
+    std::vector<double> pose((size_t)n * 7), twist((size_t)n * 6), acc((size_t)n * 6), x((size_t)n * N), P((size_t)n * N * N);
+    b->outputs(nullptr, n, pose.data(), twist.data(), acc.data(), false, 0.0);
+    b->get_state(nullptr, n, x.data(), P.data());
+    for (long s = 0; s < n; ++s) {
+      const std::string id = std::to_string(b->slot_id(s));
+      auto row = [&](const char* name, const double* v, int w) {
+        std::ofstream f((log_dir_ + "/" + name + "_" + id).c_str(), std::ios::app);
+        for (int c = 0; c < w; ++c) f << v[c] << " ";
+        f << "\n";
+      };
+      const double t = b->clock() + 0.0;  // batch clock; per-target offsets only differ for targets created later
+      double tt = t;
+      row("time", &tt, 1);
+      row("est_pose", &pose[(size_t)s * 7], 7);
+      row("est_twist", &twist[(size_t)s * 6], 6);
+      row("est_acc", &acc[(size_t)s * 6], 6);
+      std::vector<double> diag((size_t)N);
+      for (int r = 0; r < N; ++r) diag[(size_t)r] = P[((size_t)s * N + r) * N + r];
+      row("cov_diag", diag.data(), N);
+    }
+  }
+}
 
 std::vector<unsigned> TargetManager::getAvailableTargets() {
   std::vector<unsigned> ids;

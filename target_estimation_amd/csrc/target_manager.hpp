@@ -56,7 +56,14 @@ class TargetManager {
   bool getTargetTwist(unsigned id, double* twist6);         // :263-272
   bool getTargetAcceleration(unsigned id, double* acc6);    // :274-283
   long long getNumberMeasurements(unsigned id);             // :285-295
-  void log();                                               // :120-124 (rt_logger is out of scope: no-op)
+  // :120-124.  The reference publishes measurement / pose / twist / acceleration / covariance of every
+  // target through rt_logger (an external ROS package, target_interface.cpp:32-55), out of scope here.
+  // Equivalent observability without ROS: if a log directory is set (setLogDirectory or env
+  // TARGET_ESTIMATION_LOG_DIR), every log() appends one row per target to <dir>/time_<id>,
+  // est_pose_<id>, est_twist_<id>, est_acc_<id>, cov_diag_<id> in the space-separated text format of
+  // writeTxtFile (utils.hpp:96-120) that matlab/plot_target_manager_test.m reads.  Otherwise a no-op.
+  void log();
+  void setLogDirectory(const std::string& dir) { log_dir_ = dir; }
   std::vector<unsigned> getAvailableTargets();              // :126-133
   bool selectTargetType(const std::string& type_str, target_t& type);  // :52-65
 
@@ -126,6 +133,7 @@ class TargetManager {
   hipStream_t stream_ = nullptr;
   bool verbose_ = false;
   int filters_length_ = 250;
+  std::string log_dir_;
 };
 
 }  // namespace te

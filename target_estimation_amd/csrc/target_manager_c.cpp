@@ -106,6 +106,10 @@ int target_manager_set_stream(target_manager_c* self, void* hip_stream) {
   return guarded("target_manager_set_stream", [&] { M(self)->setStream((hipStream_t)hip_stream); });
 }
 
+int target_manager_set_log_directory(target_manager_c* self, const char* dir) {
+  return guarded("target_manager_set_log_directory", [&] { M(self)->setLogDirectory(dir ? dir : ""); });
+}
+
 int target_manager_synchronize(target_manager_c* self) {
   return guarded("target_manager_synchronize", [&] { M(self)->synchronize(); });
 }

@@ -268,6 +268,10 @@ class TargetManager:
     def log(self):
         self._lib.target_manager_log(self._h)
 
+    def set_log_directory(self, path):
+        _check(self._lib.target_manager_set_log_directory(self._h, None if path is None else str(path).encode()),
+               "target_manager_set_log_directory")
+
     def size(self):
         return self._lib.target_manager_size(self._h)
 

@@ -79,3 +79,25 @@ def _nmeas(orc_target):
     import ctypes as C
     # n_meas is the long long after (model, n, m, initialized, id): offset 24 (see te_oracle.h)
     return C.cast(orc_target.base + 24, C.POINTER(C.c_longlong))[0]
+
+
+def test_log_snapshots(tmp_path, models):
+    """target_manager_log with a log directory: one appended row per target and call, in the text format
+    of the reference's writeTxtFile (utils.hpp:96-120)."""
+    mgr = te.TargetManager(model_path("uniform_acceleration"))
+    ids = np.array([4, 9], dtype=np.uint32)
+    p0 = np.array([[1.0, 2, 3, 0, 0, 0, 1], [4, 5, 6, 0, 0, 0, 1]])
+    mgr.init_batch(ids, 0.004, 0.0, p0)
+    mgr.log()                                   # no directory: no-op
+    assert not list(tmp_path.iterdir())
+    mgr.set_log_directory(tmp_path)
+    for k in range(3):
+        mgr.update_batch(ids, 0.004, p0)
+        mgr.log()
+    est = np.loadtxt(tmp_path / "est_pose_9")
+    assert est.shape == (3, 7)
+    pose, _, _, _ = mgr.get_est_batch(ids)
+    np.testing.assert_allclose(est[-1], pose[1], rtol=1e-5)
+    assert np.loadtxt(tmp_path / "cov_diag_4").shape == (3, 9)
+    np.testing.assert_allclose(np.loadtxt(tmp_path / "time_4"), [0.004, 0.008, 0.012], rtol=1e-9)
+    mgr.close()
