@@ -77,7 +77,8 @@ long target_manager_get_available_targets(target_manager_c* self, unsigned int* 
 
 /* ---- array-of-ids calls, host buffers ---------------------------------------------------- */
 /* for i < n: has_meas[i] ? update(ids[i], dt, meas[i]) : update(ids[i], dt); meas [n][7] may be
- * NULL (predict only), has_meas may be NULL (all measured).  ids must be distinct.
+ * NULL (predict only), has_meas may be NULL (all measured).  An id that appears twice is stepped twice,
+ * in order, as the reference's loop would.
  * Returns the number of known ids stepped. */
 long target_manager_update_meas_batch(target_manager_c* self, const unsigned int* ids, long n, double dt,
                                       const double* meas, const unsigned char* has_meas);

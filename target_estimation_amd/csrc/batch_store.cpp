@@ -484,6 +484,13 @@ long long Batch::n_measurements(long slot) {
   return (long long)v + nm_acc_;
 }
 
+void Batch::times(double* out) {
+  if (n_ == 0) return;
+  TE_HIP_CHECK(hipMemcpyAsync(out, d_tbase_, sizeof(double) * n_, hipMemcpyDeviceToHost, stream_));
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));
+  for (long i = 0; i < n_; ++i) out[i] += t_acc_;
+}
+
 double Batch::time(long slot) {
   double v = 0;
   TE_HIP_CHECK(hipMemcpyAsync(&v, d_tbase_ + slot, sizeof(double), hipMemcpyDeviceToHost, stream_));

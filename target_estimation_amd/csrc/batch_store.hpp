@@ -89,6 +89,7 @@ class Batch {
   void set_state(const int* slots, long n, const double* x, const double* P, const double* unwrap);
   long long n_measurements(long slot);
   double time(long slot);
+  void times(double* out);   // filter time of every slot (host array [size()])
   void synchronize();
 
   // bytes of HBM one predict+update cycle must move for one target (state read+write + the

@@ -130,6 +130,8 @@ void TargetManager::log() {
     std::vector<double> pose((size_t)n * 7), twist((size_t)n * 6), acc((size_t)n * 6), x((size_t)n * N), P((size_t)n * N * N);
     b->outputs(nullptr, n, pose.data(), twist.data(), acc.data(), false, 0.0);
     b->get_state(nullptr, n, x.data(), P.data());
+    std::vector<double> times((size_t)n);
+    b->times(times.data());
     for (long s = 0; s < n; ++s) {
       const std::string id = std::to_string(b->slot_id(s));
       auto row = [&](const char* name, const double* v, int w) {
@@ -137,9 +139,7 @@ void TargetManager::log() {
         for (int c = 0; c < w; ++c) f << v[c] << " ";
         f << "\n";
       };
-      const double t = b->clock() + 0.0;  // batch clock; per-target offsets only differ for targets created later
-      double tt = t;
-      row("time", &tt, 1);
+      row("time", &times[(size_t)s], 1);
       row("est_pose", &pose[(size_t)s * 7], 7);
       row("est_twist", &twist[(size_t)s * 6], 6);
       row("est_acc", &acc[(size_t)s * 6], 6);
@@ -385,15 +385,40 @@ long TargetManager::updateBatch(const unsigned* ids, long n, double dt, const do
   }
   std::vector<std::vector<int>> slots(nb);
   std::vector<std::vector<long>> src(nb);
+  std::vector<std::vector<unsigned char>> seen(nb);
+  for (size_t b = 0; b < nb; ++b) seen[b].assign((size_t)batches_[b]->size(), 0);
   long done = 0;
+  auto flush = [&](size_t b) {
+    const long k = (long)slots[b].size();
+    if (!k) return;
+    std::vector<double> m2;
+    std::vector<unsigned char> h2;
+    if (meas) {
+      m2.resize((size_t)k * 7);
+      for (long j = 0; j < k; ++j) std::memcpy(&m2[(size_t)j * 7], meas + src[b][(size_t)j] * 7, sizeof(double) * 7);
+    }
+    if (has_meas) {
+      h2.resize((size_t)k);
+      for (long j = 0; j < k; ++j) h2[(size_t)j] = has_meas[src[b][(size_t)j]];
+    }
+    batches_[b]->step_indexed(slots[b].data(), k, dt, meas ? m2.data() : nullptr, has_meas ? h2.data() : nullptr);
+    for (int s : slots[b]) seen[b][(size_t)s] = 0;
+    slots[b].clear();
+    src[b].clear();
+  };
   for (long i = 0; i < n; ++i) {
     Loc loc;
     if (!find(ids[i], loc)) {
       if (verbose_) std::cout << "Target(" << ids[i] << ") does not exist!" << std::endl;
       continue;
     }
-    slots[(size_t)loc.batch].push_back(loc.slot);
-    src[(size_t)loc.batch].push_back(i);
+    const size_t b = (size_t)loc.batch;
+    // the same id twice in one call = two consecutive steps, as the reference's loop over ids would
+    // do: everything queued so far for that batch goes first
+    if (seen[b][(size_t)loc.slot]) flush(b);
+    seen[b][(size_t)loc.slot] = 1;
+    slots[b].push_back(loc.slot);
+    src[b].push_back(i);
     ++done;
   }
   for (size_t b = 0; b < nb; ++b) {

@@ -294,3 +294,27 @@ def test_by_ids_batch_equals_scalar_calls(models, name):
     for tid in ids[:5]:
         assert a.getNumberMeasurements(tid) == b.getNumberMeasurements(tid)
     a.close(); b.close()
+
+
+def test_duplicate_ids_in_one_batch_call_step_twice(models):
+    """An id listed twice in target_manager_update_meas_batch is stepped twice, in order (what the
+    reference's loop over ids would do), not raced."""
+    name = "uniform_acceleration"
+    m = models[name]
+    dt = 0.004
+    p0, meas = synth_stream(name, 6, 3, seed=4)
+    ids = np.arange(6, dtype=np.uint32)
+    mgr = te.TargetManager(model_path(name))
+    mgr.init_batch(ids, dt, 0.0, p0)
+    orc = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], p0, dt)
+    call_ids = np.array([0, 1, 2, 1, 3, 1, 4, 5, 0], dtype=np.uint32)
+    call_meas = np.stack([meas[k % 3][i] for k, i in enumerate(call_ids)])
+    assert mgr.update_batch(call_ids, dt, call_meas) == len(call_ids)
+    for k, i in enumerate(call_ids):                       # the oracle, one target at a time, same order
+        one = np.zeros(6, dtype=np.uint8); one[i] = 1
+        full = np.zeros((6, 7)); full[i] = call_meas[k]
+        # step only target i: emulate with a per-target oracle view
+        orc._f("orc_target_add_measurement")(orc._at(int(i)), dt, full[i].ctypes.data_as(oracle.oracle.C.POINTER(oracle.oracle.C.c_double)))
+    check_state(mgr, ids, orc, "f64", "duplicates")
+    assert mgr.getNumberMeasurements(1) == 3 and mgr.getNumberMeasurements(0) == 2 and mgr.getNumberMeasurements(5) == 1
+    mgr.close()
