@@ -14,8 +14,10 @@
  * All arrays are caller-owned; the library never keeps the pointers.
  *
  * Behavioural notes versus the reference (details in INTEGRATION.md):
- *   - every filter step executes on the GPU (one HIP launch per call on the one-target entry
- *     points; the batched entry points of target_batch_c.h are the fast path);
+ *   - every filter step executes on the GPU.  The one-target update calls are queued and executed
+ *     as one indexed launch at the next call that reads or touches the batch (a getter, a batched
+ *     call, target_manager_synchronize); per-target order is preserved, results are identical.  The
+ *     batched entry points of target_batch_c.h are the fast path;
  *   - target_manager_new returns NULL (after printing the reason) where the reference lets a
  *     C++ exception escape through extern "C" (src/target_manager.cpp:114-115);
  *   - get_est_* leave the output array untouched for an unknown id (the reference copies a

@@ -34,9 +34,6 @@ Batch::Batch(int type, int dtype, int lanes, const double* Q, const double* R, h
   }
   TE_HIP_CHECK(hipMalloc(&d_qr_, host.size()));
   TE_HIP_CHECK(hipMemcpy(d_qr_, host.data(), host.size(), hipMemcpyHostToDevice));
-  TE_HIP_CHECK(hipHostMalloc((void**)&h_ring_idx_, sizeof(int) * kRing, hipHostMallocMapped));
-  TE_HIP_CHECK(hipHostMalloc((void**)&h_ring_meas_, sizeof(double) * 8 * kRing, hipHostMallocMapped));
-  TE_HIP_CHECK(hipHostMalloc((void**)&h_ring_out_, sizeof(double) * 32, hipHostMallocMapped));
 }
 
 Batch::~Batch() {
@@ -46,7 +43,7 @@ Batch::~Batch() {
   (void)hipFree(d_qr_); (void)hipFree(d_rec_); (void)hipFree(d_tbase_); (void)hipFree(d_nmbase_);
   (void)hipFree(d_idx_); (void)hipFree(d_aos_); (void)hipFree(d_meas_); (void)hipFree(d_mask_); (void)hipFree(d_P0_);
   (void)hipFree(d_gate_ring_); (void)hipFree(d_gate_sum_); (void)hipFree(d_gate_state_); (void)hipFree(d_gate_prev_);
-  (void)hipHostFree(h_ring_idx_); (void)hipHostFree(h_ring_meas_); (void)hipHostFree(h_ring_out_);
+  (void)hipFree(d_dtper_);
 }
 
 bool Batch::same_params(int type, const double* Q, const double* R) const {
@@ -55,7 +52,10 @@ bool Batch::same_params(int type, const double* Q, const double* R) const {
          std::memcmp(R, R_.data(), R_.size() * sizeof(double)) == 0;
 }
 
-void Batch::synchronize() { TE_HIP_CHECK(hipStreamSynchronize(stream_)); }
+void Batch::synchronize() {
+  flush();
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));
+}
 
 long Batch::algorithmic_bytes_per_cycle() const {
   const long n = ops_->L.n;
@@ -103,7 +103,8 @@ void Batch::stage_reserve(long n) {
   if (n <= stage_cap_) return;
   const long want = std::max(n, stage_cap_ * 2);
   TE_HIP_CHECK(hipStreamSynchronize(stream_));
-  (void)hipFree(d_idx_); (void)hipFree(d_aos_); (void)hipFree(d_meas_); (void)hipFree(d_mask_);
+  (void)hipFree(d_idx_); (void)hipFree(d_aos_); (void)hipFree(d_meas_); (void)hipFree(d_mask_); (void)hipFree(d_dtper_);
+  TE_HIP_CHECK(hipMalloc((void**)&d_dtper_, sizeof(double) * want));
   TE_HIP_CHECK(hipMalloc((void**)&d_idx_, sizeof(int) * want));
   TE_HIP_CHECK(hipMalloc((void**)&d_aos_, sizeof(double) * 19 * want));
   TE_HIP_CHECK(hipMalloc((void**)&d_meas_, elem_size() * 7 * want));
@@ -117,6 +118,7 @@ void Batch::upload_slots(const int* slots, long n) {
 
 long Batch::append(long count, const unsigned* ids, double t0, const double* P0, bool per_target_P0,
                    const double* p0, const double* v0, const double* a0) {
+  touch();
   if (count <= 0) return n_;
   const long first = n_;
   const int N = ops_->L.n;
@@ -154,6 +156,7 @@ long Batch::append(long count, const unsigned* ids, double t0, const double* P0,
 }
 
 unsigned Batch::erase_slot(long slot) {
+  touch();
   const long last = n_ - 1;
   unsigned moved = slot_ids_[(size_t)slot];
   if (slot != last) {
@@ -169,6 +172,7 @@ unsigned Batch::erase_slot(long slot) {
 }
 
 void Batch::step_dense(double dt, const void* meas_dev, long ld, const unsigned char* has_dev) {
+  touch();
   if (n_ == 0) return;
   StepParams p;
   p.rec = d_rec_; p.qr = d_qr_; p.n = n_; p.idx = nullptr; p.meas = meas_dev; p.meas_ld = ld;
@@ -185,6 +189,7 @@ void Batch::drop_graphs() {
 
 void Batch::step_sequence(long n_ticks, double dt, const void* meas_base, long tick_stride, long ld,
                           const unsigned char* has_base, long has_stride, int use_graph) {
+  touch();
   if (n_ == 0 || n_ticks <= 0) return;
   const size_t es = elem_size();
   auto params = [&](long s) {
@@ -224,6 +229,7 @@ void Batch::step_sequence(long n_ticks, double dt, const void* meas_base, long t
 
 void Batch::step_fused(long n_ticks, double dt, const void* meas_base, long tick_stride, long ld,
                        const unsigned char* has_base, long has_stride) {
+  touch();
   if (n_ == 0 || n_ticks <= 0) return;
   StepParams p;
   p.rec = d_rec_; p.qr = d_qr_; p.n = n_; p.idx = nullptr; p.meas = meas_base; p.meas_ld = ld;
@@ -236,6 +242,7 @@ void Batch::step_fused(long n_ticks, double dt, const void* meas_base, long tick
 }
 
 void Batch::step_indexed(const int* slots, long n, double dt, const double* meas_aos, const unsigned char* has) {
+  touch();
   if (n <= 0) return;
   stage_reserve(n);
   upload_slots(slots, n);
@@ -254,6 +261,7 @@ void Batch::step_indexed(const int* slots, long n, double dt, const double* meas
 }
 
 void Batch::step_dense_host(double dt, const double* meas_aos, const unsigned char* has) {
+  touch();   // before the staging buffers are filled: a pending flush uses them too
   if (n_ == 0) return;
   stage_reserve(n_);
   if (meas_aos) {
@@ -267,27 +275,51 @@ void Batch::step_dense_host(double dt, const double* meas_aos, const unsigned ch
 }
 
 void Batch::step_one(long slot, double dt, const double* meas7) {
-  // one-target call of the reference C ABI: inputs go through a pinned, device-visible ring so
-  // the launch is asynchronous and needs no staging copy
-  if (ring_head_ == kRing) {
-    TE_HIP_CHECK(hipStreamSynchronize(stream_));
-    ring_head_ = 0;
+  if (pending_mark_.size() < (size_t)n_) pending_mark_.resize((size_t)n_, 0);
+  if (pending_mark_[(size_t)slot]) flush();   // second step of the same target: keep the caller's order
+  Pending p;
+  p.slot = (int)slot; p.has = meas7 ? 1 : 0; p.dt = dt;
+  for (int c = 0; c < 7; ++c) p.meas[c] = meas7 ? meas7[c] : 0.0;
+  pending_.push_back(p);
+  pending_mark_[(size_t)slot] = 1;
+  cache_valid_ = false;
+}
+
+void Batch::flush() {
+  const long k = (long)pending_.size();
+  if (!k) return;
+  std::vector<int> slots((size_t)k);
+  std::vector<double> dts((size_t)k), meas((size_t)k * 7);
+  std::vector<unsigned char> has((size_t)k);
+  bool all_has = true, any_has = false;
+  for (long j = 0; j < k; ++j) {
+    const Pending& p = pending_[(size_t)j];
+    slots[(size_t)j] = p.slot; dts[(size_t)j] = p.dt; has[(size_t)j] = p.has;
+    for (int c = 0; c < 7; ++c) meas[(size_t)j * 7 + c] = p.meas[c];
+    all_has = all_has && p.has;
+    any_has = any_has || p.has;
+    pending_mark_[(size_t)p.slot] = 0;
   }
-  const int k = ring_head_++;
-  h_ring_idx_[k] = (int)slot;
-  void* mslot = h_ring_meas_ + 8 * k;
-  if (meas7) {
-    if (dtype_ == F64) for (int c = 0; c < 7; ++c) static_cast<double*>(mslot)[c] = meas7[c];
-    else for (int c = 0; c < 7; ++c) static_cast<float*>(mslot)[c] = (float)meas7[c];
+  pending_.clear();
+  stage_reserve(k);
+  upload_slots(slots.data(), k);
+  TE_HIP_CHECK(hipMemcpyAsync(d_dtper_, dts.data(), sizeof(double) * k, hipMemcpyHostToDevice, stream_));
+  if (any_has) {
+    TE_HIP_CHECK(hipMemcpyAsync(d_aos_, meas.data(), sizeof(double) * 7 * k, hipMemcpyHostToDevice, stream_));
+    ops_->pack_meas(d_aos_, k, d_meas_, k, stream_);
+    if (!all_has) TE_HIP_CHECK(hipMemcpyAsync(d_mask_, has.data(), (size_t)k, hipMemcpyHostToDevice, stream_));
   }
   StepParams p;
-  p.rec = d_rec_; p.qr = d_qr_; p.n = 1; p.idx = h_ring_idx_ + k; p.meas = meas7 ? mslot : nullptr; p.meas_ld = 1;
-  p.has_meas = nullptr; p.dt_per = nullptr; p.dt = dt; p.t_base = d_tbase_; p.nm_base = d_nmbase_;
+  p.rec = d_rec_; p.qr = d_qr_; p.n = k; p.idx = d_idx_; p.meas = any_has ? d_meas_ : nullptr; p.meas_ld = k;
+  p.has_meas = (any_has && !all_has) ? d_mask_ : nullptr; p.dt_per = d_dtper_; p.dt = 0.0;
+  p.t_base = d_tbase_; p.nm_base = d_nmbase_;
   ops_->step(p, stream_);
   TE_HIP_CHECK(hipGetLastError());
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));   // the staging vectors above go out of scope
 }
 
 void Batch::outputs(const int* slots, long n, double* pose, double* twist, double* acc, bool at_time, double t1) {
+  flush();
   if (n <= 0) return;
   stage_reserve(n);
   if (slots) upload_slots(slots, n);
@@ -304,6 +336,7 @@ void Batch::outputs(const int* slots, long n, double* pose, double* twist, doubl
 }
 
 void Batch::outputs_dev(double* pose_dev, double* twist_dev, double* acc_dev, bool at_time, double t1) {
+  flush();
   if (n_ == 0) return;
   OutArgs a;
   a.rec = d_rec_; a.idx = nullptr; a.n = n_; a.pose = pose_dev; a.twist = twist_dev; a.acc = acc_dev;
@@ -313,27 +346,25 @@ void Batch::outputs_dev(double* pose_dev, double* twist_dev, double* acc_dev, bo
 }
 
 void Batch::outputs_one(long slot, double* pose, double* twist, double* acc, bool at_time, double t1) {
-  // the ring entry must stay untouched until the kernel has run: synchronise before reuse
-  if (ring_head_ == kRing) {
-    TE_HIP_CHECK(hipStreamSynchronize(stream_));
-    ring_head_ = 0;
+  flush();
+  const int one = (int)slot;
+  if (at_time || n_ > kCacheMax) {
+    outputs(&one, 1, pose, twist, acc, at_time, t1);
+    return;
   }
-  const int k = ring_head_++;
-  h_ring_idx_[k] = (int)slot;
-  OutArgs a;
-  a.rec = d_rec_; a.idx = h_ring_idx_ + k; a.n = 1;
-  a.pose = pose ? h_ring_out_ : nullptr; a.twist = twist ? h_ring_out_ + 7 : nullptr; a.acc = acc ? h_ring_out_ + 13 : nullptr;
-  a.at_time = at_time ? 1 : 0; a.t1 = t1; a.t_acc = t_acc_; a.t_base = d_tbase_;
-  ops_->outputs(a, stream_);
-  TE_HIP_CHECK(hipGetLastError());
-  TE_HIP_CHECK(hipStreamSynchronize(stream_));
-  ring_head_ = 0;  // everything queued has completed
-  if (pose) std::memcpy(pose, h_ring_out_, sizeof(double) * 7);
-  if (twist) std::memcpy(twist, h_ring_out_ + 7, sizeof(double) * 6);
-  if (acc) std::memcpy(acc, h_ring_out_ + 13, sizeof(double) * 6);
+  // small batch (the reference's scale): one kernel + one copy serve every getter until the next step
+  if (!cache_valid_) {
+    cache_out_.resize((size_t)n_ * 19);
+    outputs(nullptr, n_, cache_out_.data(), cache_out_.data() + 7 * n_, cache_out_.data() + 13 * n_, false, 0.0);
+    cache_valid_ = true;
+  }
+  if (pose) std::memcpy(pose, &cache_out_[(size_t)slot * 7], sizeof(double) * 7);
+  if (twist) std::memcpy(twist, &cache_out_[(size_t)n_ * 7 + (size_t)slot * 6], sizeof(double) * 6);
+  if (acc) std::memcpy(acc, &cache_out_[(size_t)n_ * 13 + (size_t)slot * 6], sizeof(double) * 6);
 }
 
 void Batch::intersect(const int* slots, long n, double t1, const double* origin, double radius, double* delta, double* pose) {
+  flush();
   if (n <= 0) return;
   stage_reserve(n);
   if (slots) upload_slots(slots, n);
@@ -350,6 +381,7 @@ void Batch::intersect(const int* slots, long n, double t1, const double* origin,
 }
 
 void Batch::intersect_dev(double t1, const double* origin, double radius, double* delta_dev, double* pose_dev) {
+  flush();
   if (n_ == 0) return;
   IntersectArgs a;
   a.rec = d_rec_; a.idx = nullptr; a.n = n_; a.t1 = t1;
@@ -404,6 +436,7 @@ void Batch::gate_move(long src, long dst) {
 
 void Batch::intersect_gated(const int* slots, long n, double t1, const double* origin, double radius, double pos_th,
                             double ang_th, int window, double* delta, double* pose, unsigned char* converged, double* filt) {
+  flush();
   if (n <= 0) return;
   gate_reserve(window);
   stage_reserve(n);
@@ -446,6 +479,7 @@ void Batch::pack_meas_dev(const double* aos_dev, long n, void* soa_dev, long ld)
 }
 
 void Batch::get_state(const int* slots, long n, double* x, double* P) {
+  flush();
   if (n <= 0) return;
   const int N = ops_->L.n;
   stage_reserve(n);
@@ -463,6 +497,7 @@ void Batch::get_state(const int* slots, long n, double* x, double* P) {
 }
 
 void Batch::set_state(const int* slots, long n, const double* x, const double* P, const double* unwrap) {
+  touch();
   if (n <= 0) return;
   const int N = ops_->L.n;
   stage_reserve(n);
@@ -478,6 +513,7 @@ void Batch::set_state(const int* slots, long n, const double* x, const double* P
 }
 
 long long Batch::n_measurements(long slot) {
+  flush();
   int v = 0;
   TE_HIP_CHECK(hipMemcpyAsync(&v, d_nmbase_ + slot, sizeof(int), hipMemcpyDeviceToHost, stream_));
   TE_HIP_CHECK(hipStreamSynchronize(stream_));
@@ -485,6 +521,7 @@ long long Batch::n_measurements(long slot) {
 }
 
 void Batch::times(double* out) {
+  flush();
   if (n_ == 0) return;
   TE_HIP_CHECK(hipMemcpyAsync(out, d_tbase_, sizeof(double) * n_, hipMemcpyDeviceToHost, stream_));
   TE_HIP_CHECK(hipStreamSynchronize(stream_));
@@ -492,6 +529,7 @@ void Batch::times(double* out) {
 }
 
 double Batch::time(long slot) {
+  flush();
   double v = 0;
   TE_HIP_CHECK(hipMemcpyAsync(&v, d_tbase_ + slot, sizeof(double), hipMemcpyDeviceToHost, stream_));
   TE_HIP_CHECK(hipStreamSynchronize(stream_));

@@ -59,7 +59,12 @@ class Batch {
                   const unsigned char* has_base, long has_stride);
   // One tick over the listed slots, host inputs (meas rows follow the order of `slots`).
   void step_indexed(const int* slots, long n, double dt, const double* meas_aos, const unsigned char* has);
+  // One-target call of the reference's C ABI (target_manager_update / update_meas).  The step is
+  // QUEUED: it runs, together with every other queued one-target step, as a single indexed launch
+  // when anything reads or otherwise touches the batch (flush()).  A slot queued twice flushes first,
+  // so the order of steps per target is the caller's order.
   void step_one(long slot, double dt, const double* meas7);
+  void flush();
   // One tick over every slot in slot order, host inputs (rows of meas_aos / has follow the slot order)
   void step_dense_host(double dt, const double* meas_aos, const unsigned char* has);
 
@@ -145,12 +150,15 @@ class Batch {
   std::vector<GraphEntry> graphs_;
   hipStream_t cap_stream_ = nullptr;
   void drop_graphs();
-  // pinned, device-visible ring for the one-target calls of the reference's C ABI
-  static constexpr int kRing = 1024;
-  int ring_head_ = 0;
-  int* h_ring_idx_ = nullptr;
-  double* h_ring_meas_ = nullptr;  // kRing x 8 doubles of storage (T values packed at the front)
-  double* h_ring_out_ = nullptr;   // 19 doubles + time + count
+  // queue of one-target steps (reference C ABI) and the cache that serves the one-target getters
+  struct Pending { int slot; unsigned char has; double dt; double meas[7]; };
+  std::vector<Pending> pending_;
+  std::vector<unsigned char> pending_mark_;
+  double* d_dtper_ = nullptr;
+  static constexpr long kCacheMax = 16384;   // batches up to this size cache all outputs per flush
+  std::vector<double> cache_out_;            // [n][19]: pose7 | twist6 | acc6
+  bool cache_valid_ = false;
+  void touch() { flush(); cache_valid_ = false; }   // call before anything that changes state
 };
 
 }  // namespace te
