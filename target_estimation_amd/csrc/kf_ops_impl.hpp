@@ -5,6 +5,7 @@
 #include "kf_step.hpp"
 #include "kf_step_sep.hpp"
 
+#include <cstdlib>
 #include <stdexcept>
 
 namespace te {
@@ -21,23 +22,29 @@ struct OpsImpl {
     a.dt_per = p.dt_per; a.dt = p.dt; a.t_base = p.t_base; a.nm_base = p.nm_base;
     a.n_ticks = p.n_ticks; a.tick_stride = p.tick_stride; a.has_stride = p.has_stride;
     const long waves = (p.n + C::TPW - 1) / C::TPW;
-    const unsigned blocks = (unsigned)((waves + C::WPB - 1) / C::WPB);
+    static const long small_grid = [] { const char* e = std::getenv("TE_SMALL_GRID_WAVES"); return e ? std::atol(e) : 1024L; }();
+    // small (latency-bound) grids: one wavefront per workgroup spreads the waves over more CUs
+    const int wpb_dense = waves <= small_grid ? 1 : C::WPB;
+    const unsigned blocks = (unsigned)((waves + wpb_dense - 1) / wpb_dense);
     if (p.n_ticks > 1 && p.idx) throw std::runtime_error("target_estimation_amd: fused multi-tick launches are dense only");
     if constexpr (C::SEP) {
-      const unsigned b4 = (unsigned)((waves + 3) / 4);
+      // small (latency-bound) grids: one wavefront per workgroup spreads the waves over more CUs
+      const int wpb = waves <= small_grid ? 1 : 4;
+      const unsigned b4 = (unsigned)((waves + wpb - 1) / wpb);
+      const dim3 blk(64 * wpb);
       if (p.n_ticks > 1)
-        hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, false, true>), dim3(b4), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, false, true>), dim3(b4), blk, 0, s, a);
       else if (p.idx)
-        hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, true>), dim3(b4), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, true>), dim3(b4), blk, 0, s, a);
       else
-        hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, false>), dim3(b4), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, false>), dim3(b4), blk, 0, s, a);
     } else {
       if (p.n_ticks > 1)
-        hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, false, true>), dim3(blocks), dim3(C::WPB * 64), 0, s, a);
+        hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, false, true>), dim3(blocks), dim3(wpb_dense * 64), 0, s, a);
       else if (p.idx)
-        hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, true>), dim3(blocks), dim3(C::WPB * 64), 0, s, a);
+        hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, true>), dim3(blocks), dim3(wpb_dense * 64), 0, s, a);
       else
-        hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, false>), dim3(blocks), dim3(C::WPB * 64), 0, s, a);
+        hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, false>), dim3(blocks), dim3(wpb_dense * 64), 0, s, a);
     }
   }
   static void init(const InitArgs& a, hipStream_t s) {

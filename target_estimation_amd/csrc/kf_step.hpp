@@ -111,7 +111,8 @@ __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kern
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const long wg = (long)blockIdx.x * kStepWaves + wave;  // wavefront-global index
+  // the launcher may use fewer wavefronts per workgroup than the LDS arrays are sized for (small grids)
+  const long wg = (long)blockIdx.x * (blockDim.x >> 6) + wave;  // wavefront-global index
   if (wg * TPW >= a.n) return;                           // wave-uniform
   const int g = lane / G;
   const int i = (G == 1) ? 0 : lane % G;
