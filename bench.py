@@ -238,7 +238,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": res["dtype"], "data": "synthetic",
-        "config": {"workload": res["desc"], "name": res["name"], "model": res["model"],
+        "config": {"workload": res["desc"], "name": res["name"], "motion_model": res["model"],
                    "targets_per_gpu": res["targets_per_gpu"], "targets_total": res["targets_per_gpu"] * world,
                    "lanes_per_target": res["lanes_per_target"], "P_layout": res["layout"], "dt": 0.004, "launch_mode": res["launch_mode"],
                    "sharding": "contiguous id ranges per rank, no data-path collective"},
