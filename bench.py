@@ -58,6 +58,103 @@ WORKLOADS = {
 }
 
 
+# BASELINE.json configs[3] / configs[4]: mixed populations, two batches per GPU, per-GPU share of 10^6 targets
+# over 8 GPUs.  (name: list of (model, targets per GPU)); cfg5 adds the sphere-intersection query every tick.
+MIXED = {
+    "cfg4": ("configs[3]: 62500 angular-rates + 62500 angular-velocities targets per GPU (10^6 over 8 GPUs), fp32",
+             [("angular_rates", 62_500), ("angular_velocities", 62_500)], "f32", 20240004, False),
+    "cfg5": ("configs[4]: 62500 angular-rates + 62500 uniform-acceleration targets per GPU + sphere intersection every tick, fp32",
+             [("angular_rates", 62_500), ("uniform_acceleration", 62_500)], "f32", 20240005, True),
+}
+
+
+def run_mixed(te, torch, name, steps, warmup, dist=None, rank=0, world=1, stream_ticks=16, scale=1):
+    """Two batches in one manager, one step launch per batch per tick (+ one intersection launch per batch for
+    cfg5).  Returns cycles/s over both batches; algorithmic bytes are the sum of the batches' figures."""
+    import numpy as np
+    from target_estimation_amd.streams import make_stream
+    desc, parts, dtype, seed, intersect = MIXED[name]
+    mgr = te.TargetManager(dtype=dtype)
+    mgr.set_stream(torch.cuda.current_stream().cuda_stream)
+    dt = 1.0 / 250.0
+    ticks = min(stream_ticks, steps + warmup)
+    streams, base = [], 0
+    for k, (model, n) in enumerate(parts):
+        n *= scale
+        mt = te.MODEL_TYPES[model]
+        st = make_stream(mt, n, ticks, dt, seed + 1000 * rank + 17 * k)
+        ids = np.arange(n, dtype=np.uint32) + base + rank * 10_000_000
+        base += n
+        params = _model_params(model)
+        mgr.init_batch(ids, dt, 0.0, st["p0"].cpu().numpy(), None, None, type=mt, Q=params["Q"], R=params["R"], P0=params["P"])
+        streams.append((mt, st))
+    batches = mgr.batches()
+    assert len(batches) == len(parts)
+    meas = [st["meas"].to(b.torch_dtype()).contiguous() for (_, st), b in zip(streams, batches)]
+    origin = np.zeros(3)
+    outs = [(torch.empty(b.size, dtype=torch.float64, device="cuda"), torch.empty((b.size, 7), dtype=torch.float64, device="cuda"))
+            for b in batches] if intersect else None
+    lib = mgr._lib
+
+    def tick(s):
+        for j, b in enumerate(batches):
+            b.step(dt, meas[j][s % ticks])
+            if intersect:
+                lib.target_batch_intersect_sphere_dev(b._h, float("nan"), origin.ctypes.data_as(te.capi.c_double_p), 1.0,
+                                                      outs[j][0].data_ptr(), outs[j][1].data_ptr())
+
+    for s in range(warmup):
+        tick(s)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for s in range(steps):
+        tick(warmup + s)
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    dev_ms = ev0.elapsed_time(ev1)
+    n_total = sum(b.size for b in batches)
+    alg = sum(b.algorithmic_bytes * b.size for b in batches)
+    if intersect:
+        alg += sum((b.state_dim + 1 + 8) * 8 * b.size for b in batches)   # query: read x (+t), write delta + pose7 (doubles out)
+    for b in batches:
+        p, _, _ = b.get_est(twist=False, acc=False)
+        assert torch.isfinite(p).all()
+    res = dict(name=name, desc=desc, model="+".join(m for m, _ in parts), dtype=dtype, targets_per_gpu=n_total,
+               lanes_per_target=1, layout="+".join(b.layout for b in batches), elapsed_s=elapsed, ms_per_step=elapsed * 1e3 / steps,
+               cycles_per_s=n_total * world * steps / elapsed, device_ms_per_launch=dev_ms / steps,
+               algorithmic_bytes_per_cycle=alg / n_total, algorithmic_bytes_per_launch=alg,
+               achieved_gbs=alg / (dev_ms * 1e-3 / steps) / 1e9, resident_bytes_per_target=0.0, launch_mode="python")
+    if intersect:
+        hit = sum(int((o[0] > -1).sum()) for o in outs)
+        res["intersections_last_tick"] = hit
+    mgr.close()
+    return res
+
+
+def _model_params(model):
+    """Q, R, P0 of a shipped model file (row-major), through the oracle's YAML reader-independent path."""
+    import yaml
+    import numpy as np
+    with open(os.path.join(ROOT, "models", "model_%s_params.yaml" % model)) as f:
+        node = yaml.safe_load(f)
+    n = {"uniform_velocity": 6, "uniform_acceleration": 9, "angular_velocities": 12, "angular_rates": 18}[model]
+    m = 3 if n in (6, 9) else 6
+    return dict(Q=np.array(node["Q"]).reshape(n, n), R=np.array(node["R"]).reshape(m, m), P=np.array(node["P"]).reshape(n, n))
+
+
 def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None, rank=0, world=1, stream_ticks=32,
                  launch_mode="graph"):
     from target_estimation_amd.streams import make_stream
@@ -206,10 +303,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + sorted(MIXED))
     ap.add_argument("--lanes", type=int, default=0, help="lanes per target (0 = tuned default)")
     ap.add_argument("--targets", type=int, default=0, help="override targets per GPU")
-    ap.add_argument("--extra", default="uv1m,ua1m,av1m,ar1m,ar1m_sp,av1m_sp,cfg2_full,uv1m_full,uv1m_packed,ar1m_full", help="comma list of extra workloads reported under 'extra' (N=1 only; '' = none)")
+    ap.add_argument("--extra", default="cfg3,cfg4,cfg5,uv1m,ua1m,av1m,ar1m,ar1m_sp,av1m_sp,cfg2_full,uv1m_full,uv1m_packed,ar1m_full", help="comma list of extra workloads reported under 'extra' (N=1 only; '' = none)")
     ap.add_argument("--extra-steps", type=int, default=50)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--launch-mode", default="graph", choices=["python", "sequence", "graph", "fused"],
@@ -229,9 +326,13 @@ def main():
         dist = dist_mod
     import target_estimation_amd as te
 
-    res = run_workload(te, torch, args.workload, args.steps, args.warmup, args.lanes, args.targets or None,
-                       dist, rank, world, launch_mode=args.launch_mode)
-    mgr = res.pop("_mgr")
+    if args.workload in MIXED:
+        res = run_mixed(te, torch, args.workload, args.steps, args.warmup, dist, rank, world)
+        mgr = None
+    else:
+        res = run_workload(te, torch, args.workload, args.steps, args.warmup, args.lanes, args.targets or None,
+                           dist, rank, world, launch_mode=args.launch_mode)
+        mgr = res.pop("_mgr")
     out = {
         "metric": "KF predict+update cycles/sec over N targets",
         "value": res["cycles_per_s"], "unit": "cycles/s",
@@ -246,7 +347,8 @@ def main():
                      "frac": res["achieved_gbs"] / HBM_PEAK_GBS, "traffic": None,
                      "kernel": ("kf_step_sep_kernel<%s,%s>" % (res["model"], res["dtype"]) if res["layout"] == "axis_separable"
                                 else "kf_step_kernel<%s,%s,G=%d,%s>" % (res["model"], res["dtype"], res["lanes_per_target"], res["layout"])),
-                     "survey_full_P_bytes_per_cycle": FULL_P_BYTES[res["model"]] * (8 if res["dtype"] == "f64" else 4),
+                     "survey_full_P_bytes_per_cycle": (FULL_P_BYTES[res["model"]] * (8 if res["dtype"] == "f64" else 4)
+                                                       if res["model"] in FULL_P_BYTES else None),
                      "algorithmic_bytes_per_cycle": res["algorithmic_bytes_per_cycle"],
                      "algorithmic_bytes_per_launch": res["algorithmic_bytes_per_launch"],
                      "device_ms_per_launch": res["device_ms_per_launch"]},
@@ -261,11 +363,18 @@ def main():
     except (OSError, ValueError):
         pass
     if world == 1 and rank == 0:
-        if not args.no_cpu:
+        if not args.no_cpu and args.workload in WORKLOADS:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.targets or None)
         extras = []
         for name in [e for e in args.extra.split(",") if e]:
             if name == args.workload:
+                continue
+            if name in MIXED:
+                r = run_mixed(te, torch, name, max(args.extra_steps, 200), 20)
+                extras.append({k: r[k] for k in ("name", "desc", "dtype", "targets_per_gpu", "lanes_per_target", "layout", "cycles_per_s",
+                                                "ms_per_step", "device_ms_per_launch", "achieved_gbs",
+                                                "algorithmic_bytes_per_cycle")} | {"roofline_frac": r["achieved_gbs"] / HBM_PEAK_GBS})
+                torch.cuda.empty_cache()
                 continue
             small = WORKLOADS[name][3] <= 20000
             r = run_workload(te, torch, name, 1920 if small else args.extra_steps, 64 if small else 10, 0,

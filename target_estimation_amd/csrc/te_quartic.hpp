@@ -6,94 +6,125 @@
 // the smallest real part, or -1 if none.  (The caller maps a negative result to -1 as well,
 // src/intersection_solver.cpp:83.)
 //
-// Eigen finds the roots as eigenvalues of the companion matrix; here they come from an
-// Aberth-Ehrlich iteration in complex double followed by a real Newton polish, so simple real
-// roots get an exactly zero imaginary part (as a real Schur form gives them) and conjugate pairs
-// keep theirs.  Near-multiple roots (tangent trajectories) are classified against the 1e-10
-// threshold by whatever error the solver leaves -- solver-specific in the reference too, unpinned.
+// Eigen finds the roots as eigenvalues of the companion matrix.  Only the real roots matter, so
+// here the line is split at the real critical points (roots of the derivative, themselves found the
+// same way from the roots of the second derivative, a quadratic); on each of the resulting monotone
+// intervals a sign change brackets exactly one simple real root, which a safeguarded Newton
+// iteration converges to full double precision.  The first root from the left is the answer.
+// Cost: a few hundred flops, independent of how badly scaled the coefficients are (a tiny
+// leading coefficient, i.e. a nearly unaccelerated target, sends two roots towards infinity; an
+// iteration on all four complex roots then needs hundreds of steps).
+// A multiple root (trajectory tangent to the sphere: p = p' = 0) has no sign change and is
+// reported as "no real root"; an eigen-solver returns such a pair with imaginary parts of order
+// sqrt(eps), also beyond the reference's 1e-10 threshold.  Solver-specific either way: unpinned.
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace te {
 
-struct Cplx { double re, im; };
-__device__ __forceinline__ Cplx cadd(Cplx a, Cplx b) { return {a.re + b.re, a.im + b.im}; }
-__device__ __forceinline__ Cplx csub(Cplx a, Cplx b) { return {a.re - b.re, a.im - b.im}; }
-__device__ __forceinline__ Cplx cmul(Cplx a, Cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
-__device__ __forceinline__ Cplx cdiv(Cplx a, Cplx b) {
-  // Smith's algorithm
-  if (fabs(b.re) >= fabs(b.im)) {
-    const double r = b.im / b.re, d = b.re + b.im * r;
-    return {(a.re + a.im * r) / d, (a.im - a.re * r) / d};
+// value and derivative of c[0] + c[1] x + ... + c[deg] x^deg (Horner)
+__device__ __forceinline__ void poly_eval(const double* c, int deg, double x, double* f, double* df) {
+  double v = c[deg], d = 0.0;
+  for (int k = deg - 1; k >= 0; --k) {
+    d = d * x + v;
+    v = v * x + c[k];
   }
-  const double r = b.re / b.im, d = b.re * r + b.im;
-  return {(a.re * r + a.im) / d, (a.im * r - a.re) / d};
+  *f = v;
+  *df = d;
 }
-__device__ __forceinline__ double cabs1(Cplx a) { return hypot(a.re, a.im); }
+
+// the root in (lo, hi) of a polynomial that is monotone there, given f(lo) = flo with the opposite sign of
+// f(hi): Newton steps, replaced by bisection whenever they would leave the bracket or converge slowly
+__device__ inline double poly_root_in(const double* c, int deg, double lo, double hi, double flo) {
+  // Brackets can span many orders of magnitude (the Cauchy bound of a nearly degenerate quartic is
+  // huge): first shrink them geometrically, so that the Newton phase starts within a factor 4.
+  double f, df;
+  if (lo < 0.0 && hi > 0.0) {                 // split at zero: f(0) = c[0]
+    if (c[0] == 0.0) return 0.0;
+    if ((c[0] < 0.0) == (flo < 0.0)) { lo = 0.0; flo = c[0]; } else hi = 0.0;
+  }
+  for (int it = 0; it < 96; ++it) {
+    const double al = fabs(lo), ah = fabs(hi);
+    const double mn = fmin(al, ah), mx = fmax(al, ah);
+    if (mx <= 4.0 * mn || mx < 1e-300) break;
+    const double sgn = (lo + hi) < 0.0 ? -1.0 : 1.0;
+    const double x = sgn * (mn > 0.0 ? sqrt(mn) * sqrt(mx) : mx * 9.765625e-4);
+    poly_eval(c, deg, x, &f, &df);
+    if (f == 0.0) return x;
+    if ((f < 0.0) == (flo < 0.0)) { lo = x; flo = f; } else hi = x;
+  }
+  double xl = flo < 0.0 ? lo : hi, xh = flo < 0.0 ? hi : lo;   // f(xl) < 0 < f(xh)
+  double x = 0.5 * (lo + hi);
+  double dxold = fabs(hi - lo), dx = dxold;
+  poly_eval(c, deg, x, &f, &df);
+  for (int it = 0; it < 200; ++it) {
+    if (f == 0.0) break;
+    if (f < 0.0) xl = x; else xh = x;
+    const bool outside = ((x - xh) * df - f) * ((x - xl) * df - f) > 0.0;
+    if (outside || fabs(2.0 * f) > fabs(dxold * df)) {
+      dxold = dx;
+      dx = 0.5 * (xh - xl);
+      x = xl + dx;
+    } else {
+      dxold = dx;
+      dx = f / df;
+      x -= dx;
+    }
+    if (fabs(dx) <= 2.0 * 2.220446049250313e-16 * fabs(x) || dx == 0.0) break;
+    poly_eval(c, deg, x, &f, &df);
+  }
+  return x;
+}
+
+// ascending simple real roots of a polynomial of degree `deg` inside (-B, B), given the ascending real roots
+// `crit` of its derivative (which split the line into monotone pieces); returns their number
+__device__ inline int roots_between(const double* c, int deg, const double* crit, int ncrit, double B, double* out,
+                                    int max_roots) {
+  int n = 0;
+  double lo = -B, flo, d;
+  poly_eval(c, deg, lo, &flo, &d);
+  for (int k = 0; k <= ncrit; ++k) {
+    const double hi = (k < ncrit) ? crit[k] : B;
+    if (!(hi > lo)) continue;
+    double fhi;
+    poly_eval(c, deg, hi, &fhi, &d);
+    if ((flo < 0.0 && fhi > 0.0) || (flo > 0.0 && fhi < 0.0)) {
+      out[n++] = poly_root_in(c, deg, lo, hi, flo);
+      if (n >= max_roots) return n;
+    }
+    lo = hi;
+    if (fhi != 0.0) flo = fhi;   // exactly zero at a critical point = multiple root: not a simple real root
+  }
+  return n;
+}
 
 // coefficients lowest order first: c[0] + c[1] x + ... + c[4] x^4
 __device__ inline double lowest_real_root_quartic(const double* c) {
   if (!(fabs(c[4]) > 0.0)) return -1.0;
-  double a[5];
+  // every root (and, by Gauss-Lucas, every root of the derivatives) lies in (-B, B)
+  double B = 0.0;
 #pragma unroll
-  for (int i = 0; i < 5; ++i) a[i] = c[i] / c[4];
-  double rad = 0.0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) rad = fmax(rad, fabs(a[i]));
-  rad = 1.0 + rad;
-  Cplx z[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    double s, co;
-    sincos(2.0 * 3.14159265358979323846 * i / 4.0 + 0.4, &s, &co);
-    z[i] = {0.5 * rad * co, 0.5 * rad * s};
-  }
-  for (int it = 0; it < 200; ++it) {
-    double maxstep = 0.0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      Cplx p = {1.0, 0.0}, dp = {0.0, 0.0};
-#pragma unroll
-      for (int k = 3; k >= 0; --k) {
-        dp = cadd(cmul(dp, z[i]), p);
-        p = cadd(cmul(p, z[i]), Cplx{a[k], 0.0});
-      }
-      if (p.re == 0.0 && p.im == 0.0) continue;
-      const Cplx ratio = cdiv(p, dp);
-      Cplx sum = {0.0, 0.0};
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (j != i) sum = cadd(sum, cdiv(Cplx{1.0, 0.0}, csub(z[i], z[j])));
-      const Cplx step = cdiv(ratio, csub(Cplx{1.0, 0.0}, cmul(ratio, sum)));
-      z[i] = csub(z[i], step);
-      maxstep = fmax(maxstep, cabs1(step) / (1.0 + cabs1(z[i])));
-    }
-    if (maxstep < 1e-16) break;
-  }
-  bool found = false;
-  double best = 0.0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    double re = z[i].re, im = z[i].im;
-    if (fabs(im) <= 1e-7 * (1.0 + fabs(re))) {
-      // real Newton polish: a simple real root converges and is then exactly real
-      double x = re;
-      bool ok = false;
-      for (int k = 0; k < 8; ++k) {
-        const double p = (((x + a[3]) * x + a[2]) * x + a[1]) * x + a[0];
-        const double dp = ((4.0 * x + 3.0 * a[3]) * x + 2.0 * a[2]) * x + a[1];
-        const double mag = (((fabs(x) + fabs(a[3])) * fabs(x) + fabs(a[2])) * fabs(x) + fabs(a[1])) * fabs(x) + fabs(a[0]);
-        if (fabs(p) <= 64.0 * 2.220446049250313e-16 * mag) { ok = true; break; }
-        if (dp == 0.0) break;
-        x -= p / dp;
-      }
-      if (ok && fabs(x - re) <= 1e-6 * (1.0 + fabs(re))) { re = x; im = 0.0; }
-    }
-    if (fabs(im) < 1e-10) {
-      if (!found || re < best) { best = re; found = true; }
+  for (int i = 0; i < 4; ++i) B = fmax(B, fabs(c[i] / c[4]));
+  B += 1.0;
+  const double d1[4] = {c[1], 2.0 * c[2], 3.0 * c[3], 4.0 * c[4]};        // p'
+  const double d2[3] = {d1[1], 2.0 * d1[2], 3.0 * d1[3]};                  // p''
+  // roots of the quadratic p'' (stable form), ascending
+  double r2[2];
+  int n2 = 0;
+  {
+    const double qa = d2[2], qb = d2[1], qc = d2[0];
+    const double disc = qb * qb - 4.0 * qa * qc;
+    if (disc > 0.0) {
+      const double qq = -0.5 * (qb + (qb >= 0.0 ? sqrt(disc) : -sqrt(disc)));
+      double x0 = qq / qa, x1 = (qq != 0.0) ? qc / qq : x0;
+      if (x0 > x1) { const double t = x0; x0 = x1; x1 = t; }
+      r2[0] = x0; r2[1] = x1; n2 = 2;
     }
   }
-  return found ? best : -1.0;
+  double r1[3], r0[4];
+  const int n1 = roots_between(d1, 3, r2, n2, B, r1, 3);   // critical points of p
+  const int n0 = roots_between(c, 4, r1, n1, B, r0, 1);    // the leftmost real root of p is enough
+  return n0 > 0 ? r0[0] : -1.0;
 }
 
 }  // namespace te
