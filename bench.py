@@ -260,6 +260,33 @@ def host_threads(omp_max):
     return max(1, n)
 
 
+def launch_floor(torch, nbytes, reps=32, rounds=40):
+    """Period of a DEPENDENT launch on this box: a trivial in-place read-modify-write of `nbytes` (the tick's
+    working set), `reps` launches recorded in a graph and replayed.  No tick over that working set can be
+    shorter with one launch per tick; it bounds the roofline fraction of launch-bound (small) batches."""
+    buf = torch.zeros(max(1, nbytes // 8), dtype=torch.float64, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            buf.mul_(1.0000001)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            buf.mul_(1.0000001)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(rounds):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / (reps * rounds)
+
+
 def cpu_baseline(name, targets=None, budget_s=6.0):
     """The CPU oracle (oracle/, the 'port' of the reference's Eigen path) with OpenMP over targets
     on this box's host cores, on a bounded sample of the same workload."""
@@ -362,6 +389,16 @@ def main():
             out["roofline"]["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
     except (OSError, ValueError):
         pass
+    if world == 1 and rank == 0 and res["targets_per_gpu"] <= 200000:
+        try:
+            floor_s = launch_floor(torch, int(res["algorithmic_bytes_per_launch"] // 2))
+            rf = out["roofline"]
+            rf["launch_floor_ms"] = floor_s * 1e3
+            rf["launch_floor_note"] = ("period of a trivial dependent read-modify-write launch over the same working set, graph-replayed; "
+                                       "a launch-bound tick cannot beat it")
+            rf["frac_at_launch_floor"] = res["algorithmic_bytes_per_launch"] / floor_s / 1e9 / HBM_PEAK_GBS
+        except Exception as exc:   # never let the diagnostic break the bench line
+            out["roofline"]["launch_floor_error"] = str(exc)[:200]
     if world == 1 and rank == 0:
         if not args.no_cpu and args.workload in WORKLOADS:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.targets or None)
