@@ -242,3 +242,74 @@ def test_full_size_properties(models, wl):
     assert (np.diagonal(P2, axis1=1, axis2=2)[:, :3] >= np.diagonal(P, axis1=1, axis2=2)[:, :3]).all()
     assert mgr.getNumberMeasurements(int(tail[-1])) == ticks
     mgr.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_randomised_schedule_against_oracle(models, seed):
+    """Seeded fuzz over everything at once: random model / precision / layout, random SPD Q, R, P0
+    (decoupled or coupled), random dt per tick, random masks, and a random mix of dense device
+    ticks, by-id batches in random order, queued one-target calls (some targets twice) and
+    predict-everything ticks; the state is compared with the oracle at the end of every schedule."""
+    rng = np.random.default_rng(seed)
+    for trial in range(6):
+        name = HARNESS_ORDER[int(rng.integers(4))]
+        dtype = "f64" if rng.random() < 0.6 else "f32"
+        m = models[name]
+        n = m["Q"].shape[0]
+        if rng.random() < 0.5:                       # coupled matrices -> dense kernel
+
+            def spd(A, s):
+                B = rng.normal(size=A.shape) * s
+                d = np.sqrt(np.diag(A))
+                return A + (B @ B.T) * np.outer(d, d)
+            Q, R, P0 = spd(m["Q"], 0.3), spd(m["R"], 0.3), spd(m["P"], 0.3)
+            lanes = 0
+        else:
+            Q, R, P0 = m["Q"], m["R"], m["P"]
+            lanes = int(rng.choice([0, 201, 301] + ([3] if n in (6, 9) else [6])))
+        N = int(rng.integers(5, 300))
+        steps = 14
+        p0, meas = synth_stream(name, N, steps, seed=int(rng.integers(1 << 30)))
+        ids = (rng.permutation(5000)[:N]).astype(np.uint32)
+        mgr = te.TargetManager(dtype=dtype, lanes_per_target=lanes)
+        mgr.init_batch(ids, 0.004, 0.0, p0, type=m["model"], Q=Q, R=R, P0=P0)
+        orc = oracle.OracleBatch(m["model"], Q, R, P0, p0, 0.004, dtype=dtype)
+        b = mgr.batches()[0]
+        for s in range(steps):
+            dt = float(rng.choice([0.004, 0.001, 0.02, 0.0]))
+            mode = int(rng.integers(4))
+            if mode == 0:                            # dense device tick with a mask
+                mask = (rng.random(N) < 0.8).astype(np.uint8)
+                b.step(dt, to_soa(meas[s], b), torch.from_numpy(mask).cuda())
+                orc.step(dt, meas[s], mask)
+            elif mode == 1:                          # by-id batch in random order, subset
+                sub = rng.permutation(N)[: max(1, N * 2 // 3)]
+                mask = (rng.random(len(sub)) < 0.7).astype(np.uint8)
+                mgr.update_batch(ids[sub], dt, meas[s][sub], mask)
+                for j, i in enumerate(sub):
+                    _one(orc, int(i), dt, meas[s][i] if mask[j] else None)
+            elif mode == 2:                          # queued one-target calls, some targets twice
+                calls = [(int(i), bool(rng.random() < 0.8)) for i in rng.choice(N, size=min(N, 9))]
+                for i, has in calls:
+                    mgr.update(int(ids[i]), dt, meas[s][i] if has else None)
+                    _one(orc, i, dt, meas[s][i] if has else None)
+            else:                                    # predict everything (TargetManager::update(dt))
+                mgr.update_all(dt)
+                orc.step(dt, None)
+        x, P = mgr.get_state_batch(ids)
+        xo, Po = orc.state()
+        t = TOL[dtype]
+        scale = np.abs(Po).max(axis=(1, 2), keepdims=True)
+        assert np.isfinite(x).all()
+        assert (np.abs(x - xo) <= 10 * (t["x_atol"] + t["x_rtol"] * np.abs(xo))).all(), (name, dtype, lanes)
+        assert (np.abs(P - Po) / scale).max() <= 10 * t["P_rel"], (name, dtype, lanes)
+        mgr.close()
+
+
+def _one(orc, i, dt, meas_row):
+    import ctypes as C
+    if meas_row is None:
+        orc._f("orc_target_update")(orc._at(i), float(dt))
+    else:
+        row = np.ascontiguousarray(meas_row, dtype=np.float64)
+        orc._f("orc_target_add_measurement")(orc._at(i), float(dt), row.ctypes.data_as(C.POINTER(C.c_double)))
