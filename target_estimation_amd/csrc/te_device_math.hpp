@@ -32,19 +32,29 @@ template <> struct Mth<float> {
 
 template <typename T> __device__ __forceinline__ constexpr T pi_v() { return (T)3.14159265358979323846; }
 
+// fmod(t, 2pi) for the reference's angle helpers.  IEEE fmod is exact, so wherever the quotient is
+// known to be 0 or 1 the result can be formed without the (long, especially in fp64) library
+// routine and is bit-identical: |t| < 2pi -> t;  2pi <= t < 4pi -> t - 2pi (exact by Sterbenz).
+template <typename T> __device__ __forceinline__ T fmod_2pi(T t) {
+  const T two_pi = 2 * pi_v<T>();
+  if (t > -two_pi && t < two_pi) return t;
+  if (t >= two_pi && t < 2 * two_pi) return t - two_pi;
+  return Mth<T>::fmod(t, two_pi);
+}
+
 // geometry.hpp:31-36 constrainAngle
 template <typename T> __device__ __forceinline__ T constrain_angle(T x) {
   const T pi = pi_v<T>();
-  x = Mth<T>::fmod(x + pi, 2 * pi);
+  x = fmod_2pi(x + pi);
   if (x < 0) x += 2 * pi;
   return x - pi;
 }
 // geometry.hpp:43-45 angleConv
-template <typename T> __device__ __forceinline__ T angle_conv(T a) { return Mth<T>::fmod(constrain_angle(a), 2 * pi_v<T>()); }
+template <typename T> __device__ __forceinline__ T angle_conv(T a) { return fmod_2pi(constrain_angle(a)); }
 // geometry.hpp:53-58 angleDiff
 template <typename T> __device__ __forceinline__ T angle_diff(T a, T b) {
   const T pi = pi_v<T>();
-  T d = Mth<T>::fmod(b - a + pi, 2 * pi);
+  T d = fmod_2pi(b - a + pi);
   if (d < 0) d += 2 * pi;
   return d - pi;
 }
