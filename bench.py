@@ -334,6 +334,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="lanes per target (0 = tuned default)")
     ap.add_argument("--targets", type=int, default=0, help="override targets per GPU")
     ap.add_argument("--extra", default="cfg3,cfg4,cfg5,uv1m,ua1m,av1m,ar1m,ar1m_sp,av1m_sp,cfg2_full,uv1m_full,uv1m_packed,ar1m_full", help="comma list of extra workloads reported under 'extra' (N=1 only; '' = none)")
+    ap.add_argument("--extra-multi", default="uv1m,ua1m,av1m,ar1m,cfg4",
+                    help="extra workloads when --gpus > 1 (per-GPU sizes; every rank runs them in lockstep)")
     ap.add_argument("--extra-steps", type=int, default=50)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--launch-mode", default="graph", choices=["python", "sequence", "graph", "fused"],
@@ -399,28 +401,31 @@ def main():
             rf["frac_at_launch_floor"] = res["algorithmic_bytes_per_launch"] / floor_s / 1e9 / HBM_PEAK_GBS
         except Exception as exc:   # never let the diagnostic break the bench line
             out["roofline"]["launch_floor_error"] = str(exc)[:200]
-    if world == 1 and rank == 0:
-        if not args.no_cpu and args.workload in WORKLOADS:
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.targets or None)
-        extras = []
-        for name in [e for e in args.extra.split(",") if e]:
-            if name == args.workload:
-                continue
-            if name in MIXED:
-                r = run_mixed(te, torch, name, max(args.extra_steps, 200), 20)
-                extras.append({k: r[k] for k in ("name", "desc", "dtype", "targets_per_gpu", "lanes_per_target", "layout", "cycles_per_s",
-                                                "ms_per_step", "device_ms_per_launch", "achieved_gbs",
-                                                "algorithmic_bytes_per_cycle")} | {"roofline_frac": r["achieved_gbs"] / HBM_PEAK_GBS})
-                torch.cuda.empty_cache()
-                continue
+    if world == 1 and rank == 0 and not args.no_cpu and args.workload in WORKLOADS:
+        out["cpu_baseline"] = cpu_baseline(args.workload, args.targets or None)
+    # Extra workloads in the same line.  One GPU: the full list.  Several GPUs: one 10^6-targets-per-GPU
+    # workload per YAML motion model plus configs[3], every rank in lockstep (same barriers, max over
+    # ranks), so that the scaling curve exists for each model and not only for the headline workload.
+    extra_names = [e for e in args.extra.split(",") if e]
+    if world > 1:
+        extra_names = [e for e in args.extra_multi.split(",") if e]
+    extras = []
+    for name in extra_names:
+        if name == args.workload:
+            continue
+        if name in MIXED:
+            r = run_mixed(te, torch, name, max(args.extra_steps, 200), 20, dist, rank, world)
+        else:
             small = WORKLOADS[name][3] <= 20000
             r = run_workload(te, torch, name, 1920 if small else args.extra_steps, 64 if small else 10, 0,
-                             launch_mode=args.launch_mode)
+                             dist=dist, rank=rank, world=world, launch_mode=args.launch_mode)
             r.pop("_mgr")
-            extras.append({k: r[k] for k in ("name", "desc", "dtype", "targets_per_gpu", "lanes_per_target", "layout", "cycles_per_s",
-                                            "ms_per_step", "device_ms_per_launch", "achieved_gbs",
-                                            "algorithmic_bytes_per_cycle")} | {"roofline_frac": r["achieved_gbs"] / HBM_PEAK_GBS})
-            torch.cuda.empty_cache()
+        extras.append({k: r[k] for k in ("name", "desc", "dtype", "targets_per_gpu", "lanes_per_target", "layout", "cycles_per_s",
+                                        "ms_per_step", "device_ms_per_launch", "achieved_gbs",
+                                        "algorithmic_bytes_per_cycle")} | {"roofline_frac": r["achieved_gbs"] / HBM_PEAK_GBS,
+                                                                            "n_gpus": world})
+        torch.cuda.empty_cache()
+    if extras:
         out["extra"] = extras
     if dist is not None:
         dist.barrier()
