@@ -156,7 +156,7 @@ def _model_params(model):
 
 
 def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None, rank=0, world=1, stream_ticks=32,
-                 launch_mode="graph"):
+                 launch_mode="graph", gather=False):
     from target_estimation_amd.streams import make_stream
     desc, model, dtype, n_targets, seed = WORKLOADS[name]
     if targets:
@@ -236,6 +236,19 @@ def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None,
         algorithmic_bytes_per_cycle=b.algorithmic_bytes, algorithmic_bytes_per_launch=alg_bytes,
         achieved_gbs=alg_bytes / launch_s / 1e9,
         resident_bytes_per_target=b.resident_bytes_per_target, launch_mode=launch_mode)
+    if gather and dist is not None:
+        from target_estimation_amd import dist as td
+        pose, _, _ = b.get_est(twist=False, acc=False)
+        if dist.get_backend() != "nccl":
+            pose = pose.cpu()
+        torch.cuda.synchronize()
+        dist.barrier()
+        tg = time.perf_counter()
+        full = td.gather_rows(pose, n_targets * world, dst=0)
+        torch.cuda.synchronize()
+        res["gather_pose_ms"] = (time.perf_counter() - tg) * 1e3
+        if rank == 0:
+            assert full.shape == (n_targets * world, 7) and bool(torch.isfinite(full).all())
     res["_mgr"] = (mgr, b, st, ids, dt)
     return res
 
@@ -338,6 +351,9 @@ def main():
                     help="extra workloads when --gpus > 1 (per-GPU sizes; every rank runs them in lockstep)")
     ap.add_argument("--extra-steps", type=int, default=50)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--gather", action="store_true",
+                    help="after the timed region, gather every rank's pose7 rows to rank 0 (RCCL gather over xGMI) and report its time; "
+                         "off by default: the predict/update path has no collective")
     ap.add_argument("--launch-mode", default="graph", choices=["python", "sequence", "graph", "fused"],
                     help="how the per-tick launches are enqueued (always one kernel launch per tick)")
     args = ap.parse_args()
@@ -360,7 +376,7 @@ def main():
         mgr = None
     else:
         res = run_workload(te, torch, args.workload, args.steps, args.warmup, args.lanes, args.targets or None,
-                           dist, rank, world, launch_mode=args.launch_mode)
+                           dist, rank, world, launch_mode=args.launch_mode, gather=args.gather)
         mgr = res.pop("_mgr")
     out = {
         "metric": "KF predict+update cycles/sec over N targets",
@@ -371,7 +387,8 @@ def main():
         "config": {"workload": res["desc"], "name": res["name"], "motion_model": res["model"],
                    "targets_per_gpu": res["targets_per_gpu"], "targets_total": res["targets_per_gpu"] * world,
                    "lanes_per_target": res["lanes_per_target"], "P_layout": res["layout"], "dt": 0.004, "launch_mode": res["launch_mode"],
-                   "sharding": "contiguous id ranges per rank, no data-path collective"},
+                   "sharding": "contiguous id ranges per rank, no data-path collective"} |
+                  ({"gather_pose_ms": res["gather_pose_ms"]} if "gather_pose_ms" in res else {}),
         "roofline": {"bound": "hbm", "achieved": res["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": res["achieved_gbs"] / HBM_PEAK_GBS, "traffic": None,
                      "kernel": ("kf_step_sep_kernel<%s,%s>" % (res["model"], res["dtype"]) if res["layout"] == "axis_separable"
