@@ -1,0 +1,29 @@
+"""A plain C program using only the reference's ten C symbols, compiled with gcc against our header
+and linked with the GPU library: the drop-in claim exercised from C, not through ctypes."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT, model_path
+
+pytestmark = pytest.mark.gpu
+
+
+def test_plain_c_caller_of_the_ten_symbols(tmp_path):
+    import torch   # the GPU box; without a device the program would (correctly) fail at target_manager_new
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    libdir = os.path.join(ROOT, "target_estimation_amd", "lib")
+    exe = str(tmp_path / "drop_in_test")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-Werror",
+                           "-I", os.path.join(ROOT, "include", "target_estimation_amd"),
+                           os.path.join(ROOT, "tests", "c_abi", "drop_in_test.c"), "-o", exe,
+                           "-L", libdir, "-ltarget_estimation_amd", "-lm", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe, model_path("uniform_velocity")], capture_output=True, text=True, timeout=300)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "drop-in test ok" in out.stdout
+    assert "Target(7) already exists!" in out.stdout
+    assert "Target(8) does not exist!" in out.stdout
