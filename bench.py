@@ -68,9 +68,10 @@ MIXED = {
 }
 
 
-def run_mixed(te, torch, name, steps, warmup, dist=None, rank=0, world=1, stream_ticks=16, scale=1):
+def run_mixed(te, torch, name, steps, warmup, dist=None, rank=0, world=1, stream_ticks=16, scale=1, launch_mode="graph"):
     """Two batches in one manager, one step launch per batch per tick (+ one intersection launch per batch for
-    cfg5).  Returns cycles/s over both batches; algorithmic bytes are the sum of the batches' figures."""
+    cfg5); in graph mode the batches are concurrent branches of one hipGraph (target_manager_step_sequence_all).
+    Returns cycles/s over both batches; algorithmic bytes are the sum of the batches' figures."""
     import numpy as np
     from target_estimation_amd.streams import make_stream
     desc, parts, dtype, seed, intersect = MIXED[name]
@@ -96,6 +97,8 @@ def run_mixed(te, torch, name, steps, warmup, dist=None, rank=0, world=1, stream
             for b in batches] if intersect else None
     lib = mgr._lib
 
+    query = (origin, 1.0, [o[0] for o in outs], [o[1] for o in outs]) if intersect else None
+
     def tick(s):
         for j, b in enumerate(batches):
             b.step(dt, meas[j][s % ticks])
@@ -103,8 +106,24 @@ def run_mixed(te, torch, name, steps, warmup, dist=None, rank=0, world=1, stream
                 lib.target_batch_intersect_sphere_dev(b._h, float("nan"), origin.ctypes.data_as(te.capi.c_double_p), 1.0,
                                                       outs[j][0].data_ptr(), outs[j][1].data_ptr())
 
-    for s in range(warmup):
-        tick(s)
+    def run(first, count):
+        """`count` ticks starting at stream position `first`: whole passes over the stream replay ONE hipGraph whose
+        branches are the batches (they run concurrently); the rest is issued eagerly."""
+        if launch_mode == "python":
+            for s in range(first, first + count):
+                tick(s)
+            return
+        s, end = first, first + count
+        while s < end:
+            o = s % ticks
+            nblk = min(ticks - o, end - s)
+            whole = launch_mode == "graph" and o == 0 and nblk == ticks
+            mgr.step_sequence_all(dt, [m[o:o + nblk] for m in meas], query=query, use_graph=1 if whole else 0)
+            s += nblk
+
+    if launch_mode == "graph":
+        mgr.step_sequence_all(dt, meas, query=query, use_graph=2)    # record before the timed region
+    run(0, warmup)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -112,8 +131,7 @@ def run_mixed(te, torch, name, steps, warmup, dist=None, rank=0, world=1, stream
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for s in range(steps):
-        tick(warmup + s)
+    run(warmup, steps)
     ev1.record()
     torch.cuda.synchronize()
     if dist is not None:
@@ -136,7 +154,8 @@ def run_mixed(te, torch, name, steps, warmup, dist=None, rank=0, world=1, stream
                lanes_per_target=1, layout="+".join(b.layout for b in batches), elapsed_s=elapsed, ms_per_step=elapsed * 1e3 / steps,
                cycles_per_s=n_total * world * steps / elapsed, device_ms_per_launch=dev_ms / steps,
                algorithmic_bytes_per_cycle=alg / n_total, algorithmic_bytes_per_launch=alg,
-               achieved_gbs=alg / (dev_ms * 1e-3 / steps) / 1e9, resident_bytes_per_target=0.0, launch_mode="python")
+               achieved_gbs=alg / (dev_ms * 1e-3 / steps) / 1e9, resident_bytes_per_target=0.0,
+               launch_mode=launch_mode)
     if intersect:
         hit = sum(int((o[0] > -1).sum()) for o in outs)
         res["intersections_last_tick"] = hit
@@ -372,7 +391,8 @@ def main():
     import target_estimation_amd as te
 
     if args.workload in MIXED:
-        res = run_mixed(te, torch, args.workload, args.steps, args.warmup, dist, rank, world)
+        res = run_mixed(te, torch, args.workload, args.steps, args.warmup, dist, rank, world,
+                        launch_mode="graph" if args.launch_mode == "fused" else args.launch_mode)
         mgr = None
     else:
         res = run_workload(te, torch, args.workload, args.steps, args.warmup, args.lanes, args.targets or None,
@@ -431,7 +451,8 @@ def main():
         if name == args.workload:
             continue
         if name in MIXED:
-            r = run_mixed(te, torch, name, max(args.extra_steps, 200), 20, dist, rank, world)
+            r = run_mixed(te, torch, name, max(args.extra_steps, 200), 20, dist, rank, world,
+                              launch_mode="graph" if args.launch_mode == "fused" else args.launch_mode)
         else:
             small = WORKLOADS[name][3] <= 20000
             r = run_workload(te, torch, name, 1920 if small else args.extra_steps, 64 if small else 10, 0,

@@ -165,6 +165,21 @@ int target_batch_step_sequence(target_batch_c* b, long n_ticks, double dt, const
  * recorded streams; its throughput is an "effective" figure, not comparable with one launch per tick. */
 int target_batch_step_fused(target_batch_c* b, long n_ticks, double dt, const void* meas_dev, long tick_stride, long ld,
                             const unsigned char* has_meas_dev, long has_stride);
+/* n_ticks ticks of EVERY batch of the manager in one call (BASELINE.json configs[3]/[4]: several motion
+ * models per GPU, optionally with the per-tick sphere query "fused on-GPU").  per_batch[i] describes
+ * batch i (target_manager_get_batch order): measurements as for target_batch_step_sequence, plus the
+ * device outputs of the query (delta [size], pose [size][7] or NULL; overwritten every tick) when
+ * query != 0.  The query is the own-time one (t1 = each target's current time).  Batches are
+ * independent; with use_graph != 0 their launch chains are recorded as parallel branches of ONE
+ * hipGraph and run concurrently (use_graph == 2: record only).  Results are identical to calling
+ * target_batch_step (+ target_batch_intersect_sphere_dev with a NaN t1) per batch per tick. */
+typedef struct target_batch_sequence_c {
+  const void* meas_dev; long tick_stride; long ld;
+  const unsigned char* has_meas_dev; long has_stride;
+  double* delta_dev; double* pose_dev;
+} target_batch_sequence_c;
+int target_manager_step_sequence_all(target_manager_c* m, long n_ticks, double dt, const target_batch_sequence_c* per_batch,
+                                     long n_batches, int query, const double* origin, double radius, int use_graph);
 /* derived outputs of every slot into device arrays of doubles ([size][7], [size][6], [size][6];
  * any may be NULL); at_time != 0 extrapolates to t1 */
 int target_batch_get_est_dev(target_batch_c* b, double* pose_dev, double* twist_dev, double* acc_dev, int at_time, double t1);

@@ -14,6 +14,13 @@ c_double_p = C.POINTER(C.c_double)
 c_ubyte_p = C.POINTER(C.c_ubyte)
 
 # every symbol include/target_estimation_amd/*.h declares: name -> (restype, argtypes)
+class BatchSequence(C.Structure):
+    """target_batch_sequence_c of target_batch_c.h"""
+    _fields_ = [("meas_dev", C.c_void_p), ("tick_stride", C.c_long), ("ld", C.c_long),
+                ("has_meas_dev", C.c_void_p), ("has_stride", C.c_long),
+                ("delta_dev", C.c_void_p), ("pose_dev", C.c_void_p)]
+
+
 SIGNATURES = {
     # target_manager_c.h (the reference's ten symbols)
     "target_manager_new": (C.c_void_p, [C.c_char_p]),
@@ -83,6 +90,7 @@ SIGNATURES = {
     "target_batch_slot_ids": (C.c_long, [C.c_void_p, c_uint_p, C.c_long]),
     "target_batch_step": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_long, C.c_void_p]),
     "target_batch_step_sequence": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_int]),
+    "target_manager_step_sequence_all": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_long, C.c_int, c_double_p, C.c_double, C.c_int]),
     "target_batch_step_fused": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long]),
     "target_batch_get_est_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double]),
     "target_batch_pack_meas_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_long]),

@@ -90,6 +90,21 @@ class Batch {
   void intersect_gated_dev(double t1, const double* origin, double radius, double pos_th, double ang_th, int window,
                            double* delta_dev, double* pose_dev, unsigned char* converged_dev);
 
+  // Building blocks of the manager's all-batches sequence (TargetManager::stepSequenceAll): enqueue
+  // n_ticks ticks -- each optionally followed by the own-time sphere query of every slot -- on `st`
+  // without touching the batch clock, then account for them.
+  struct SeqSpec {
+    const void* meas_base; long tick_stride; long ld;   // tick s reads meas_base + s*tick_stride elements, SoA [7][ld]
+    const unsigned char* has_base; long has_stride;     // optional masks
+    double* delta_dev; double* pose_dev;                // query outputs [size] / [size][7] (overwritten every tick)
+  };
+  void enqueue_sequence(hipStream_t st, long n_ticks, double dt, const SeqSpec& s, bool query, const double* origin, double radius);
+  void account_sequence(long n_ticks, double dt, bool all_measured);
+  // identity of everything a recorded launch sequence refers to
+  struct DevIdentity { const void* rec; const void* qr; const void* tbase; const void* nmbase; long n; };
+  DevIdentity dev_identity() const { return DevIdentity{d_rec_, d_qr_, d_tbase_, d_nmbase_, n_}; }
+  void prepare() { touch(); }
+
   void get_state(const int* slots, long n, double* x, double* P);
   void set_state(const int* slots, long n, const double* x, const double* P, const double* unwrap);
   long long n_measurements(long slot);

@@ -300,8 +300,11 @@ __global__ void intersect_kernel(const IntersectArgs a) {
   T x[N];
 #pragma unroll
   for (int r = 0; r < N; ++r) x[r] = state_get<C, T>(a.rec, slot, r, N);
-  const double t = a.t_base[slot] + a.t_acc;
-  const double t1 = (a.t1 != a.t1) ? t : a.t1;
+  // own-time query (t1 = NaN): the offsets are 0 and delta themselves, so a recorded launch (hipGraph)
+  // does not depend on the batch clock; the reference's (delta + t1) - t_ differs by at most ulp(t_)
+  const bool own = a.t1 != a.t1;
+  const double t = own ? 0.0 : a.t_base[slot] + a.t_acc;
+  const double t1 = own ? 0.0 : a.t1;
   T pose7[7], twist6[6], acc6[6];
   derive_outputs<M, T>(x, true, (T)(t1 - t), pose7, twist6, acc6);
   const double px = (double)pose7[0] - a.origin[0], py = (double)pose7[1] - a.origin[1], pz = (double)pose7[2] - a.origin[2];
@@ -313,8 +316,7 @@ __global__ void intersect_kernel(const IntersectArgs a) {
   c[2] = vx * vx + vy * vy + vz * vz + px * ax + py * ay + pz * az;
   c[1] = 2 * (px * vx + py * vy + pz * vz);
   c[0] = px * px + py * py + pz * pz - a.radius * a.radius;
-  double d = lowest_real_root_quartic(c);
-  if (d < 0) d = -1.0;
+  const double d = first_crossing_quartic(c);   // leftmost real root if >= 0, else -1
   a.delta[e] = d;
   if (a.pose) {
     double out[7] = {0, 0, 0, 0, 0, 0, 1};

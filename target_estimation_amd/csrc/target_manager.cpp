@@ -35,7 +35,11 @@ TargetManager::TargetManager(const std::string& file, int dtype, int lanes_per_t
     default_values_loaded_ = true;
 }
 
-TargetManager::~TargetManager() {}
+TargetManager::~TargetManager() {
+  dropSeqGraphs();
+  for (auto st : branch_streams_) (void)hipStreamDestroy(st);
+  for (auto ev : branch_events_) (void)hipEventDestroy(ev);
+}
 
 bool TargetManager::selectTargetType(const std::string& type_str, target_t& type) {
   if (type_str == "angular_rates") type = ANGULAR_RATES;
@@ -616,6 +620,94 @@ void TargetManager::setStream(hipStream_t s) {
   lock_guard<mutex> lg(target_lock_);
   for (auto& b : batches_) { b->synchronize(); b->set_stream(s); }
   stream_ = s;
+}
+
+void TargetManager::dropSeqGraphs() {
+  for (auto& g : seq_graphs_) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+  seq_graphs_.clear();
+}
+
+void TargetManager::stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpec* specs, long n_specs, bool query,
+                                    const double* origin, double radius, int use_graph) {
+  lock_guard<mutex> lg(target_lock_);
+  const size_t nb = batches_.size();
+  if ((size_t)n_specs != nb) throw std::runtime_error("target_estimation_amd: stepSequenceAll needs one spec per batch");
+  if (n_ticks <= 0 || nb == 0) return;
+  if (query && !origin) throw std::runtime_error("target_estimation_amd: stepSequenceAll: query without an origin");
+  for (size_t b = 0; b < nb; ++b) {
+    if (query && batches_[b]->size() > 0 && !specs[b].delta_dev)
+      throw std::runtime_error("target_estimation_amd: stepSequenceAll: query without a delta output");
+    batches_[b]->prepare();   // queued one-target steps run first
+  }
+  const double zero3[3] = {0, 0, 0};
+  const double* org = origin ? origin : zero3;
+  if (!use_graph) {
+    for (long s = 0; s < n_ticks; ++s)
+      for (size_t b = 0; b < nb; ++b) {
+        Batch::SeqSpec one = specs[b];
+        const size_t es = batches_[b]->elem_size();
+        if (one.meas_base) one.meas_base = static_cast<const char*>(one.meas_base) + (size_t)(s * one.tick_stride) * es;
+        if (one.has_base) one.has_base += s * one.has_stride;
+        batches_[b]->enqueue_sequence(stream_, 1, dt, one, query, org, radius);
+      }
+  } else {
+    auto same_spec = [](const Batch::SeqSpec& x, const Batch::SeqSpec& y) {
+      return x.meas_base == y.meas_base && x.tick_stride == y.tick_stride && x.ld == y.ld && x.has_base == y.has_base &&
+             x.has_stride == y.has_stride && x.delta_dev == y.delta_dev && x.pose_dev == y.pose_dev;
+    };
+    auto same_id = [](const Batch::DevIdentity& x, const Batch::DevIdentity& y) {
+      return x.rec == y.rec && x.qr == y.qr && x.tbase == y.tbase && x.nmbase == y.nmbase && x.n == y.n;
+    };
+    SeqGraph* hit = nullptr;
+    for (auto& g : seq_graphs_) {
+      if (g.n_ticks != n_ticks || g.dt != dt || g.query != query || g.specs.size() != nb) continue;
+      if (query && (g.origin[0] != org[0] || g.origin[1] != org[1] || g.origin[2] != org[2] || g.radius != radius)) continue;
+      bool ok = true;
+      for (size_t b = 0; b < nb && ok; ++b) ok = same_spec(g.specs[b], specs[b]) && same_id(g.ident[b], batches_[b]->dev_identity());
+      if (ok) { hit = &g; break; }
+    }
+    if (!hit) {
+      if (seq_graphs_.size() >= 8) dropSeqGraphs();
+      while (branch_streams_.size() < nb) {
+        hipStream_t st; TE_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        branch_streams_.push_back(st);
+      }
+      while (branch_events_.size() < nb + 1) {
+        hipEvent_t ev; TE_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        branch_events_.push_back(ev);
+      }
+      SeqGraph g;
+      g.n_ticks = n_ticks; g.dt = dt; g.query = query; g.radius = radius;
+      g.origin[0] = org[0]; g.origin[1] = org[1]; g.origin[2] = org[2];
+      g.specs.assign(specs, specs + nb);
+      for (size_t b = 0; b < nb; ++b) g.ident.push_back(batches_[b]->dev_identity());
+      g.graph = nullptr; g.exec = nullptr;
+      hipStream_t root = branch_streams_[0];
+      TE_HIP_CHECK(hipStreamBeginCapture(root, hipStreamCaptureModeThreadLocal));
+      try {
+        TE_HIP_CHECK(hipEventRecord(branch_events_[0], root));
+        for (size_t b = 1; b < nb; ++b) TE_HIP_CHECK(hipStreamWaitEvent(branch_streams_[b], branch_events_[0], 0));
+        for (size_t b = 0; b < nb; ++b) batches_[b]->enqueue_sequence(branch_streams_[b], n_ticks, dt, specs[b], query, org, radius);
+        for (size_t b = 1; b < nb; ++b) {
+          TE_HIP_CHECK(hipEventRecord(branch_events_[b], branch_streams_[b]));
+          TE_HIP_CHECK(hipStreamWaitEvent(root, branch_events_[b], 0));
+        }
+      } catch (...) {
+        hipGraph_t broken = nullptr;
+        (void)hipStreamEndCapture(root, &broken);   // leave capture mode before reporting
+        if (broken) (void)hipGraphDestroy(broken);
+        throw;
+      }
+      TE_HIP_CHECK(hipStreamEndCapture(root, &g.graph));
+      TE_HIP_CHECK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+      seq_graphs_.push_back(std::move(g));
+      hit = &seq_graphs_.back();
+    }
+    if (use_graph == 2) return;
+    TE_HIP_CHECK(hipGraphLaunch(hit->exec, stream_));
+  }
+  for (size_t b = 0; b < nb; ++b)
+    if (batches_[b]->size() > 0) batches_[b]->account_sequence(n_ticks, dt, specs[b].meas_base && !specs[b].has_base);
 }
 
 void TargetManager::synchronize() {

@@ -104,6 +104,14 @@ class TargetManager {
   long intersectBatch(const unsigned* ids, long n, double t1, const double* origin, double radius, double* delta,
                       double* pose, unsigned char* found);
 
+  // n_ticks ticks of EVERY batch (specs in batch order), device-resident inputs: one step launch per
+  // batch per tick, optionally followed by the own-time sphere query of every target.  The batches are
+  // independent, so with use_graph != 0 each batch's chain of launches is recorded on its own branch
+  // of one hipGraph (fork/join by events) and the branches run concurrently; use_graph == 2 records
+  // without launching.  use_graph == 0 issues the same launches eagerly, batch after batch per tick.
+  void stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpec* specs, long n_specs, bool query,
+                       const double* origin, double radius, int use_graph);
+
   int numBatches() const { return (int)batches_.size(); }
   Batch* batch(int i) { return batches_[(size_t)i].get(); }
   Batch* batchOfType(int type);
@@ -134,6 +142,17 @@ class TargetManager {
   bool verbose_ = false;
   int filters_length_ = 250;
   std::string log_dir_;
+  // recorded all-batches sequences (stepSequenceAll)
+  struct SeqGraph {
+    long n_ticks; double dt; bool query; double origin[3]; double radius;
+    std::vector<Batch::SeqSpec> specs;
+    std::vector<Batch::DevIdentity> ident;
+    hipGraph_t graph; hipGraphExec_t exec;
+  };
+  std::vector<SeqGraph> seq_graphs_;
+  std::vector<hipStream_t> branch_streams_;
+  std::vector<hipEvent_t> branch_events_;   // [0] = fork, [b] = join of branch b
+  void dropSeqGraphs();
 };
 
 }  // namespace te

@@ -1,130 +1,213 @@
-// te_quartic.hpp -- smallest real root of the sphere-intersection quartic, on the device.
+// te_quartic.hpp -- first crossing time of the sphere-intersection quartic, on the device.
 //
 // Reference semantics (src/intersection_solver.cpp:4-17, Eigen::PolynomialSolver from
 // unsupported/Eigen/Polynomials, not under the reference tree): if the leading coefficient is
 // zero return -1; otherwise take all roots, keep those with |imag| < 1e-10, return the one with
-// the smallest real part, or -1 if none.  (The caller maps a negative result to -1 as well,
-// src/intersection_solver.cpp:83.)
+// the smallest real part, or -1 if none.  The only caller maps a negative result to -1 as well
+// (src/intersection_solver.cpp:83), so what the query needs is
+//     first_crossing_quartic(c) = the leftmost real root if it is >= 0, else -1.
 //
-// Eigen finds the roots as eigenvalues of the companion matrix.  Only the real roots matter, so
-// here the line is split at the real critical points (roots of the derivative, themselves found the
-// same way from the roots of the second derivative, a quadratic); on each of the resulting monotone
-// intervals a sign change brackets exactly one simple real root, which a safeguarded Newton
-// iteration converges to full double precision.  The first root from the left is the answer.
-// Cost: a few hundred flops, independent of how badly scaled the coefficients are (a tiny
-// leading coefficient, i.e. a nearly unaccelerated target, sends two roots towards infinity; an
-// iteration on all four complex roots then needs hundreds of steps).
-// A multiple root (trajectory tangent to the sphere: p = p' = 0) has no sign change and is
-// reported as "no real root"; an eigen-solver returns such a pair with imaginary parts of order
-// sqrt(eps), also beyond the reference's 1e-10 threshold.  Solver-specific either way: unpinned.
+// Eigen finds the roots as eigenvalues of the companion matrix.  Only the leftmost real root matters,
+// and it can be located rigorously from the shape of the curve:
+//   1. the critical points of p (real roots of the cubic p') split the line into monotone pieces.
+//      They come from W. Kahan's cubic algorithm ("To Solve a Real Cubic Equation", 1986): ONE
+//      Newton iteration that starts outside the outermost root and converges monotonically, then
+//      deflation (forward or backward, whichever is stable) to a quadratic solved in closed form;
+//   2. with the leading coefficient made positive the leftmost root sits on the first decreasing
+//      piece that reaches below zero: (-inf, m0) or (m1, m2).  A piece that ends at or below x = 0,
+//      or on which p(0) < 0, holds a negative root: the answer is -1 without computing it;
+//   3. otherwise the inflection points of p (closed form) cut the piece into parts of constant
+//      convexity; on the part with the sign change Newton's iteration started from the correct end
+//      converges monotonically, without bracketing bookkeeping.
+// Cost: one cubic and one quartic Newton iteration of a handful of steps each plus three quadratic
+// formulas -- a few hundred fp64 instructions, against several thousand for bracketing every
+// monotone piece in turn (tools/quartic_bracketing.hpp, the earlier version); uniform across a wavefront.
+// A multiple root (trajectory tangent to the sphere: p = p' = 0) has no sign change and is reported
+// as "no real root"; an eigen-solver returns such a pair with imaginary parts of order sqrt(eps),
+// also beyond the reference's 1e-10 threshold.  Solver-specific either way: unpinned.
+//
+// The file also compiles on the host (TE_QUARTIC_HOST) for the CPU-side solver tests.
 #pragma once
+#ifdef TE_QUARTIC_HOST
+#include <cmath>
+#define TE_QDEV inline
+namespace te { namespace qdetail {
+using std::fabs; using std::fma; using std::fmax; using std::sqrt; using std::frexp; using std::ldexp;
+inline double rcp(double d) { return 1.0 / d; }
+inline float cbrt_f(float x) { return std::cbrt(x); }
+}}
+#else
 #include <hip/hip_runtime.h>
+#define TE_QDEV __device__ __forceinline__
+namespace te { namespace qdetail {
+// 1/d to about 2^-50: v_rcp_f64 and two Newton steps, no scaling / fix-up (operands here are normal)
+__device__ __forceinline__ double rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return fma(fma(-d, r, 1.0), r, r);
+}
+__device__ __forceinline__ float cbrt_f(float x) { return ::cbrtf(x); }
+}}
+#endif
 
 namespace te {
+#ifdef TE_QUARTIC_HOST
+using namespace qdetail;
+#endif
 
-// value and derivative of c[0] + c[1] x + ... + c[deg] x^deg (Horner)
-__device__ __forceinline__ void poly_eval(const double* c, int deg, double x, double* f, double* df) {
-  double v = c[deg], d = 0.0;
-  for (int k = deg - 1; k >= 0; --k) {
-    d = d * x + v;
-    v = v * x + c[k];
+// value and derivative of the quartic c[0] + c[1] x + ... + c[4] x^4 (Horner)
+TE_QDEV void quartic_eval(const double* c, double x, double* f, double* df) {
+  double v = c[4], d = 0.0;
+#pragma unroll
+  for (int k = 3; k >= 0; --k) {
+    d = fma(d, x, v);
+    v = fma(v, x, c[k]);
   }
   *f = v;
   *df = d;
 }
 
-// the root in (lo, hi) of a polynomial that is monotone there, given f(lo) = flo with the opposite sign of
-// f(hi): Newton steps, replaced by bisection whenever they would leave the bracket or converge slowly
-__device__ inline double poly_root_in(const double* c, int deg, double lo, double hi, double flo) {
-  // Brackets can span many orders of magnitude (the Cauchy bound of a nearly degenerate quartic is
-  // huge): first shrink them geometrically, so that the Newton phase starts within a factor 4.
-  double f, df;
-  if (lo < 0.0 && hi > 0.0) {                 // split at zero: f(0) = c[0]
-    if (c[0] == 0.0) return 0.0;
-    if ((c[0] < 0.0) == (flo < 0.0)) { lo = 0.0; flo = c[0]; } else hi = 0.0;
-  }
-  for (int it = 0; it < 96; ++it) {
-    const double al = fabs(lo), ah = fabs(hi);
-    const double mn = fmin(al, ah), mx = fmax(al, ah);
-    if (mx <= 4.0 * mn || mx < 1e-300) break;
-    const double sgn = (lo + hi) < 0.0 ? -1.0 : 1.0;
-    const double x = sgn * (mn > 0.0 ? sqrt(mn) * sqrt(mx) : mx * 9.765625e-4);
-    poly_eval(c, deg, x, &f, &df);
-    if (f == 0.0) return x;
-    if ((f < 0.0) == (flo < 0.0)) { lo = x; flo = f; } else hi = x;
-  }
-  double xl = flo < 0.0 ? lo : hi, xh = flo < 0.0 ? hi : lo;   // f(xl) < 0 < f(xh)
-  double x = 0.5 * (lo + hi);
-  double dxold = fabs(hi - lo), dx = dxold;
-  poly_eval(c, deg, x, &f, &df);
-  for (int it = 0; it < 200; ++it) {
-    if (f == 0.0) break;
-    if (f < 0.0) xl = x; else xh = x;
-    const bool outside = ((x - xh) * df - f) * ((x - xl) * df - f) > 0.0;
-    if (outside || fabs(2.0 * f) > fabs(dxold * df)) {
-      dxold = dx;
-      dx = 0.5 * (xh - xl);
-      x = xl + dx;
-    } else {
-      dxold = dx;
-      dx = f / df;
-      x -= dx;
+// real roots of a x^2 + b x + c (a != 0), ascending; returns 0 or 2 (a double root counts as none: the
+// callers only want points where the sign changes)
+TE_QDEV int quadratic_roots(double a, double b, double c, double* r) {
+  const double disc = fma(b, b, -4.0 * a * c);
+  if (!(disc > 0.0)) return 0;
+  const double sq = sqrt(disc);
+  const double qq = -0.5 * (b + (b >= 0.0 ? sq : -sq));
+  double x0 = qq * qdetail::rcp(a), x1 = (qq != 0.0) ? c * qdetail::rcp(qq) : x0;
+  if (x0 > x1) { const double t = x0; x0 = x1; x1 = t; }
+  r[0] = x0; r[1] = x1;
+  return 2;
+}
+
+// upper bound (within ~1e-6 above) of |t|^(1/3): float cube root of the mantissa, exponent handled exactly
+TE_QDEV double cbrt_upper(double t) {
+  t = fabs(t);
+  if (!(t > 0.0)) return 0.0;
+  int e;
+  const double m = frexp(t, &e);             // t = m 2^e, m in [0.5, 1)
+  int k = e / 3, j = e - 3 * k;              // e = 3k + j
+  if (j < 0) { j += 3; k -= 1; }
+  const float cr = qdetail::cbrt_f((float)ldexp(m, j));
+  return ldexp((double)cr * 1.000001, k);
+}
+
+// Real roots of A x^3 + B x^2 + C x + D (A != 0), ascending, after W. Kahan's QBC; returns 1 or 3
+// (a double root of the quotient quadratic is dropped: the sign of the cubic does not change there).
+TE_QDEV int cubic_real_roots(double A, double B, double C, double D, double* out) {
+  double X, b1, c2;
+  if (D == 0.0) {
+    X = 0.0; b1 = B; c2 = C;
+  } else {
+    const double rA = qdetail::rcp(A);
+    X = -(B * rA) * (1.0 / 3.0);                           // the inflection point of the cubic
+    double q0 = A * X;
+    b1 = q0 + B; c2 = fma(b1, X, C);
+    double dq = fma(q0 + b1, X, c2), q = fma(c2, X, D);
+    double t = q * rA;
+    const double s = t > 0.0 ? 1.0 : (t < 0.0 ? -1.0 : 0.0);
+    double r = cbrt_upper(t);
+    t = -dq * rA;
+    if (t > 0.0) r = 1.324717957244746 * 1.000001 * fmax(r, sqrt(t));
+    double x0 = X - s * r;                                 // outside the outermost root on the side of s
+    if (x0 != X) {
+      for (int it = 0; it < 80; ++it) {                    // monotone from outside: stops when it no longer advances
+        X = x0;
+        q0 = A * X;
+        b1 = q0 + B; c2 = fma(b1, X, C);
+        dq = fma(q0 + b1, X, c2); q = fma(c2, X, D);
+        x0 = (dq == 0.0) ? X : X - (q * qdetail::rcp(dq)) * (1.0 - 1.0e-15);
+        if (!(s * x0 > s * X)) break;
+      }
+      // deflate backwards when the root found is the large one (forward deflation would cancel)
+      if (fabs(A) * X * X > fabs(D * qdetail::rcp(X))) {
+        const double rX = qdetail::rcp(X);
+        c2 = -D * rX; b1 = (c2 - C) * rX;
+      }
     }
-    if (fabs(dx) <= 2.0 * 2.220446049250313e-16 * fabs(x) || dx == 0.0) break;
-    poly_eval(c, deg, x, &f, &df);
+  }
+  double r2[2];
+  const int n2 = quadratic_roots(A, b1, c2, r2);
+  if (n2 == 0) { out[0] = X; return 1; }
+  // merge X into the ascending pair
+  if (X <= r2[0]) { out[0] = X; out[1] = r2[0]; out[2] = r2[1]; }
+  else if (X <= r2[1]) { out[0] = r2[0]; out[1] = X; out[2] = r2[1]; }
+  else { out[0] = r2[0]; out[1] = r2[1]; out[2] = X; }
+  return 3;
+}
+
+// the root of the quartic in [lo, hi], 0 <= lo < hi, p(lo) > 0 > p(hi), p decreasing and of constant
+// convexity there: Newton from the end it converges monotonically from (convex: lo, concave: hi),
+// the bracket kept only as a guard against rounding
+TE_QDEV double quartic_root_monotone(const double* c, double lo, double hi, bool convex) {
+  double x = convex ? lo : hi;
+  double dx = hi - lo;
+  bool prev_pos = convex;                                  // sign of p at the starting end
+  for (int it = 0; it < 100; ++it) {
+    double f, df;
+    quartic_eval(c, x, &f, &df);
+    if (f == 0.0) return x;
+    const bool pos = f > 0.0;
+    // the approach is one-sided; a sign flip after a tiny step is the rounding noise of p itself: converged
+    if (pos != prev_pos && dx <= 1e-9 * fabs(x)) return x;
+    prev_pos = pos;
+    if (pos) lo = x; else hi = x;
+    double xn = (df != 0.0) ? x - f * qdetail::rcp(df) : 0.5 * (lo + hi);
+    if (!(xn >= lo && xn <= hi)) xn = 0.5 * (lo + hi);     // left the bracket (rounding, or df ~ 0): bisect
+    dx = fabs(xn - x);
+    x = xn;
+    if (dx <= 4.0 * 2.220446049250313e-16 * fabs(x)) break;
   }
   return x;
 }
 
-// ascending simple real roots of a polynomial of degree `deg` inside (-B, B), given the ascending real roots
-// `crit` of its derivative (which split the line into monotone pieces); returns their number
-__device__ inline int roots_between(const double* c, int deg, const double* crit, int ncrit, double B, double* out,
-                                    int max_roots) {
-  int n = 0;
-  double lo = -B, flo, d;
-  poly_eval(c, deg, lo, &flo, &d);
-  for (int k = 0; k <= ncrit; ++k) {
-    const double hi = (k < ncrit) ? crit[k] : B;
-    if (!(hi > lo)) continue;
-    double fhi;
-    poly_eval(c, deg, hi, &fhi, &d);
-    if ((flo < 0.0 && fhi > 0.0) || (flo > 0.0 && fhi < 0.0)) {
-      out[n++] = poly_root_in(c, deg, lo, hi, flo);
-      if (n >= max_roots) return n;
-    }
-    lo = hi;
-    if (fhi != 0.0) flo = fhi;   // exactly zero at a critical point = multiple root: not a simple real root
-  }
-  return n;
-}
-
-// coefficients lowest order first: c[0] + c[1] x + ... + c[4] x^4
-__device__ inline double lowest_real_root_quartic(const double* c) {
-  if (!(fabs(c[4]) > 0.0)) return -1.0;
-  // every root (and, by Gauss-Lucas, every root of the derivatives) lies in (-B, B)
-  double B = 0.0;
+// coefficients lowest order first: c[0] + c[1] x + ... + c[4] x^4.
+// Leftmost real root if it is >= 0, else -1 (also -1 for a zero leading coefficient and for no real root).
+TE_QDEV double first_crossing_quartic(const double* cin) {
+  if (!(fabs(cin[4]) > 0.0)) return -1.0;
+  double c[5];
+  const double sg = cin[4] < 0.0 ? -1.0 : 1.0;             // same roots, leading coefficient > 0
 #pragma unroll
-  for (int i = 0; i < 4; ++i) B = fmax(B, fabs(c[i] / c[4]));
-  B += 1.0;
-  const double d1[4] = {c[1], 2.0 * c[2], 3.0 * c[3], 4.0 * c[4]};        // p'
-  const double d2[3] = {d1[1], 2.0 * d1[2], 3.0 * d1[3]};                  // p''
-  // roots of the quadratic p'' (stable form), ascending
-  double r2[2];
-  int n2 = 0;
-  {
-    const double qa = d2[2], qb = d2[1], qc = d2[0];
-    const double disc = qb * qb - 4.0 * qa * qc;
-    if (disc > 0.0) {
-      const double qq = -0.5 * (qb + (qb >= 0.0 ? sqrt(disc) : -sqrt(disc)));
-      double x0 = qq / qa, x1 = (qq != 0.0) ? qc / qq : x0;
-      if (x0 > x1) { const double t = x0; x0 = x1; x1 = t; }
-      r2[0] = x0; r2[1] = x1; n2 = 2;
-    }
+  for (int i = 0; i < 5; ++i) c[i] = sg * cin[i];
+  // critical points of p, ascending
+  double m[3];
+  const int k = cubic_real_roots(4.0 * c[4], 3.0 * c[3], 2.0 * c[2], c[1], m);
+  double f, df;
+  // the first decreasing piece (L, H) with p(L) > 0 > p(H): (-inf, m0) or (m1, m2)
+  double L, H;
+  bool have_L;
+  quartic_eval(c, m[0], &f, &df);
+  if (f < 0.0) { have_L = false; L = 0.0; H = m[0]; }
+  else {
+    if (k < 3) return -1.0;
+    quartic_eval(c, m[2], &f, &df);
+    if (!(f < 0.0)) return -1.0;
+    have_L = true; L = m[1]; H = m[2];
   }
-  double r1[3], r0[4];
-  const int n1 = roots_between(d1, 3, r2, n2, B, r1, 3);   // critical points of p
-  const int n0 = roots_between(c, 4, r1, n1, B, r0, 1);    // the leftmost real root of p is enough
-  return n0 > 0 ? r0[0] : -1.0;
+  if (!(H > 0.0)) return -1.0;                              // the root is below H <= 0
+  if (!have_L || L < 0.0) {                                 // 0 lies on the piece: p(0) = c[0] decides the side
+    if (c[0] < 0.0) return -1.0;
+    if (c[0] == 0.0) return 0.0;
+    L = 0.0;
+  }
+  // inflection points inside (L, H) narrow the piece to constant convexity
+  double infl[2];
+  const int ni = quadratic_roots(6.0 * c[4], 3.0 * c[3], c[2], infl);
+  bool convex = true;
+  if (ni == 2) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const double x = infl[j];
+      if (x > L && x < H) {
+        quartic_eval(c, x, &f, &df);
+        if (f == 0.0) return x;
+        if (f > 0.0) L = x; else H = x;
+      }
+    }
+    const double mid = 0.5 * (L + H);
+    convex = !(mid > infl[0] && mid < infl[1]);            // p'' < 0 exactly between the inflection points
+  }
+  return quartic_root_monotone(c, L, H, convex);
 }
 
 }  // namespace te

@@ -367,6 +367,32 @@ class TargetManager:
             "target_manager_intersect_sphere_converged_batch")
         return conv.astype(bool), pose, delta, filt
 
+    def step_sequence_all(self, dt, meas, has_meas=None, query=None, use_graph=True):
+        """meas: one CUDA tensor [ticks, 7, ld] per batch (batches() order): `ticks` ticks of every batch, the
+        batches' launch chains as concurrent branches of one hipGraph (use_graph) or eagerly.  query =
+        (origin[3], radius, deltas, poses) adds the own-time sphere query of every target after every step;
+        deltas[i] [size] and poses[i] [size, 7] (or None) are CUDA double tensors, overwritten every tick."""
+        nb = len(meas)          # the library checks it against the number of batches
+        ticks = meas[0].shape[0] if nb else 0
+        specs = (capi.BatchSequence * max(nb, 1))()
+        for i, t in enumerate(meas):
+            assert t.is_cuda and t.dim() == 3 and t.shape[0] == ticks and t.shape[1] == 7 and (t.shape[2] == 1 or t.stride(2) == 1)
+            specs[i].meas_dev, specs[i].tick_stride, specs[i].ld = t.data_ptr(), t.stride(0), t.stride(1)
+            if has_meas is not None and has_meas[i] is not None:
+                h = has_meas[i]
+                assert h.is_cuda and h.dim() == 2 and h.element_size() == 1 and h.shape[0] == ticks
+                specs[i].has_meas_dev, specs[i].has_stride = h.data_ptr(), h.stride(0)
+        origin, radius = None, 0.0
+        if query is not None:
+            origin, radius, deltas, poses = query
+            origin = _d(origin, (3,))
+            for i in range(nb):
+                specs[i].delta_dev = deltas[i].data_ptr()
+                specs[i].pose_dev = None if poses is None or poses[i] is None else poses[i].data_ptr()
+        _check(self._lib.target_manager_step_sequence_all(
+            self._h, ticks, float(dt), C.cast(specs, C.c_void_p), nb, 0 if query is None else 1,
+            None if origin is None else _dp(origin), float(radius), int(use_graph)), "target_manager_step_sequence_all")
+
     def batches(self):
         return [Batch(self._lib, self._lib.target_manager_get_batch(self._h, i))
                 for i in range(self._lib.target_manager_num_batches(self._h))]

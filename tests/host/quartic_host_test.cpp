@@ -1,0 +1,84 @@
+// quartic_host_test.cpp -- the device solver of the sphere-intersection quartic
+// (target_estimation_amd/csrc/te_quartic.hpp, compiled for the host) against the oracle's
+// long-double Aberth roots (oracle/te_oracle.c, orc_lowest_real_root).  Test code: links the oracle.
+#define TE_QUARTIC_HOST
+#include "../../target_estimation_amd/csrc/te_quartic.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+extern "C" double orc_lowest_real_root(const double* coeffs, int ncoeffs);
+
+static long n_cases = 0, n_class = 0, n_val = 0, n_hits = 0;
+static double worst = 0;
+
+static void check(const double* c) {
+  double want = orc_lowest_real_root(c, 5);
+  if (want < 0) want = -1;                      // the caller's mapping (src/intersection_solver.cpp:83)
+  const double got = te::first_crossing_quartic(c);
+  ++n_cases;
+  if ((want == -1) != (got == -1)) { ++n_class; printf("class: c = %.17g %.17g %.17g %.17g %.17g want %.17g got %.17g\n", c[0], c[1], c[2], c[3], c[4], want, got); return; }
+  if (want == -1) return;
+  ++n_hits;
+  const double rel = std::fabs(got - want) / std::fmax(std::fabs(want), 1e-300);
+  if (rel > worst) worst = rel;
+  if (rel > 1e-9) { ++n_val; printf("value: c = %.17g %.17g %.17g %.17g %.17g want %.17g got %.17g\n", c[0], c[1], c[2], c[3], c[4], want, got); }
+}
+
+int main() {
+  std::mt19937_64 g(7);
+  std::normal_distribution<double> N(0, 1);
+  std::uniform_real_distribution<double> U(0, 1);
+  // sphere scenes, acceleration scale swept over 14 decades (tiny leading coefficients included)
+  for (double asc : {1e2, 1.0, 1e-2, 1e-4, 1e-6, 1e-9, 1e-12})
+    for (long i = 0; i < 1500; ++i) {
+      double p[3], v[3], a[3];
+      for (int k = 0; k < 3; ++k) { p[k] = -10 + 20 * U(g); v[k] = 3 * N(g); a[k] = asc * N(g); }
+      const double R = 0.5 + 8 * U(g);
+      const double c[5] = {p[0] * p[0] + p[1] * p[1] + p[2] * p[2] - R * R, 2 * (p[0] * v[0] + p[1] * v[1] + p[2] * v[2]),
+                           v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + p[0] * a[0] + p[1] * a[1] + p[2] * a[2],
+                           v[0] * a[0] + v[1] * a[1] + v[2] * a[2], 0.25 * (a[0] * a[0] + a[1] * a[1] + a[2] * a[2])};
+      check(c);
+    }
+  // random coefficients over 12 decades, both leading signs
+  for (long i = 0; i < 8000; ++i) {
+    double c[5];
+    for (int k = 0; k < 5; ++k) c[k] = N(g) * std::pow(10.0, -6 + 12 * U(g));
+    check(c);
+  }
+  // prescribed roots (four real / two real + a complex pair / two pairs), well separated
+  for (long i = 0; i < 8000; ++i) {
+    const double lead = (U(g) < 0.5 ? -1 : 1) * std::pow(10.0, -3 + 6 * U(g));
+    double q1[3], q2[3];
+    for (double* q : {q1, q2}) {
+      if (U(g) < 0.6) { const double r1 = 10 * N(g), r2 = r1 + (0.05 + std::fabs(10 * N(g))) * (U(g) < 0.5 ? -1 : 1); q[0] = r1 * r2; q[1] = -(r1 + r2); }
+      else { const double re = 5 * N(g), im = 3 * U(g) + 0.05; q[0] = re * re + im * im; q[1] = -2 * re; }
+      q[2] = 1;
+    }
+    double c[5] = {0, 0, 0, 0, 0};
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) c[a + b] += q1[a] * q2[b];
+    for (int k = 0; k < 5; ++k) c[k] *= lead;
+    check(c);
+  }
+  // semantics
+  const double zero_lead[5] = {1, 2, 1, 0, 0};                         // leading coefficient 0 -> -1
+  const double none[5] = {1, 0, 1, 0, 1};                              // x^4 + x^2 + 1: no real root
+  const double neg_first[5] = {-24 * 5, 2 * 5, 23 * 5 - 20, 8 - 5, 1};  // (x+5)(x-1)(x+... ) has a negative leftmost root
+  int bad = 0;
+  if (te::first_crossing_quartic(zero_lead) != -1) { printf("zero leading coefficient\n"); ++bad; }
+  if (te::first_crossing_quartic(none) != -1) { printf("no real root\n"); ++bad; }
+  {  // (x - 1)(x - 2)(x - 3)(x - 4) -> 1;  (x + 5)(x - 2)(x - 3)(x - 4) -> -1 (leftmost root negative)
+    const double a[5] = {24, -50, 35, -10, 1}, b[5] = {-120, 106, -9, -4, 1};
+    if (std::fabs(te::first_crossing_quartic(a) - 1.0) > 1e-12) { printf("1234\n"); ++bad; }
+    if (te::first_crossing_quartic(b) != -1) { printf("-5 2 3 4\n"); ++bad; }
+    const double z[5] = {0, -6, 11, -6, 1};                            // x (x-1)(x-2)(x-3): root exactly at 0
+    if (te::first_crossing_quartic(z) != 0.0) { printf("root at 0: %g\n", te::first_crossing_quartic(z)); ++bad; }
+  }
+  (void)neg_first;
+  printf("cases %ld (with a crossing: %ld), class mismatches %ld, value mismatches %ld, worst rel %.3g, semantics failures %d\n",
+         n_cases, n_hits, n_class, n_val, worst, bad);
+  const bool ok = n_class == 0 && n_val == 0 && bad == 0 && n_hits > 3000;
+  printf(ok ? "quartic host test ok\n" : "QUARTIC HOST TEST FAILED\n");
+  return ok ? 0 : 1;
+}

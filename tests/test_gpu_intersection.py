@@ -123,3 +123,68 @@ def test_convergence_gate_matches_oracle(models, name):
     assert n_conv > 0
     # the reference-order scalar entry (intersection_solver.hpp:98-101) goes through the same gates
     mgr.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("use_graph", [0, 1])
+def test_all_batches_sequence_equals_per_batch_calls(models, dtype, use_graph):
+    """target_manager_step_sequence_all (the batches as concurrent branches of one hipGraph, with the per-tick
+    own-time sphere query) == one target_batch_step + one intersect call per batch per tick, bit for bit."""
+    from target_estimation_amd.streams import make_stream
+    names = ["angular_rates", "uniform_acceleration", "angular_velocities"]
+    sizes = [333, 1000, 77]
+    ticks, dt = 6, 0.004
+    origin, radius = np.array([0.1, -0.2, 0.3]), 5.0
+
+    def build():
+        mgr = te.TargetManager(dtype=dtype)
+        mgr.set_stream(torch.cuda.current_stream().cuda_stream)
+        base, meas = 0, []
+        for k, (name, n) in enumerate(zip(names, sizes)):
+            m = models[name]
+            p0, v0, a0 = scene(n, 40 + k)
+            ids = np.arange(n, dtype=np.uint32) + base
+            base += n
+            mgr.init_batch(ids, dt, 0.0, p0, v0, a0, type=te.MODEL_TYPES[name], Q=m["Q"], R=m["R"], P0=m["P"])
+            st = make_stream(te.MODEL_TYPES[name], n, ticks, dt, 7 + k)
+            mm = st["meas"].clone()
+            mm[:, :3, :] = torch.as_tensor(p0[:, :3].T.copy(), device="cuda")[None] + 0.01 * mm[:, :3, :]
+            meas.append(mm.to(torch.float64 if dtype == "f64" else torch.float32).contiguous())
+        return mgr, meas
+
+    ref, meas = build()
+    rb = ref.batches()
+    assert len(rb) == 3
+    for s in range(ticks):
+        for j, b in enumerate(rb):
+            b.step(dt, meas[j][s])
+    want = [b.intersect_sphere(origin, radius) for b in rb]
+
+    mgr, meas2 = build()
+    bs = mgr.batches()
+    deltas = [torch.full((b.size,), 123.0, dtype=torch.float64, device="cuda") for b in bs]
+    poses = [torch.zeros((b.size, 7), dtype=torch.float64, device="cuda") for b in bs]
+    poses[2] = None                                            # pose output is optional per batch
+    half = ticks // 2
+    for part in (slice(0, half), slice(half, ticks)):          # two calls: the second one replays nothing stale
+        mgr.step_sequence_all(dt, [m[part] for m in meas2], query=(origin, radius, deltas, poses), use_graph=use_graph)
+    torch.cuda.synchronize()
+    for j in range(3):
+        xr, Pr = ref.get_state_batch(np.arange(sizes[j], dtype=np.uint32) + sum(sizes[:j]))
+        xg, Pg = mgr.get_state_batch(np.arange(sizes[j], dtype=np.uint32) + sum(sizes[:j]))
+        np.testing.assert_array_equal(xg, xr)
+        np.testing.assert_array_equal(Pg, Pr)
+        np.testing.assert_array_equal(deltas[j].cpu().numpy(), want[j][0].cpu().numpy())
+        if poses[j] is not None:
+            np.testing.assert_array_equal(poses[j].cpu().numpy(), want[j][1].cpu().numpy())
+        assert mgr.getTime(sum(sizes[:j])) == pytest.approx(ticks * dt) and ref.getTime(sum(sizes[:j])) == pytest.approx(ticks * dt)
+    assert (deltas[0] > -1).sum() > 10 and (deltas[2] == -1).all()   # AV has no acceleration: never intersects
+    assert mgr.getNumberMeasurements(0) == ticks == ref.getNumberMeasurements(0)
+    # replay of the recorded graph with the same arguments keeps stepping
+    if use_graph:
+        mgr.step_sequence_all(dt, [m[half:ticks] for m in meas2], query=(origin, radius, deltas, poses), use_graph=1)
+        assert mgr.getTime(0) == pytest.approx((ticks + ticks - half) * dt)
+    # wrong number of specs -> error, nothing launched
+    with pytest.raises(RuntimeError):
+        mgr.step_sequence_all(dt, meas2[:2])
+    ref.close(); mgr.close()
