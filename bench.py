@@ -25,13 +25,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 
 # lanes-per-target tuned on MI355X (tools/sweep.py): small, latency-bound batches want more lanes per
 # target, large HBM-bound ones fewer.  0 = the library default.
-# 0 = automatic: the shipped models' Q, R, P0 do not couple axes, so the library picks the exact
-# axis-separable layout.  The *_full / *_packed workloads force the dense kernel (what general
-# matrices get): full P, or symmetric-packed P (101 = 1 + TARGET_LAYOUT_SYMMETRIC_PACKED).
-# 301 = axis-separable with symmetric-packed group blocks (1 + TARGET_LAYOUT_AXIS_SEPARABLE_PACKED): P is then
-# symmetric by construction (the automatic layout keeps the reference's rounding-level asymmetry).
+# 0 = automatic: the shipped models' Q, R, P0 are symmetric and do not couple axes, so the library picks the
+# axis-separable layout with symmetric-packed group blocks (301 = 1 + TARGET_LAYOUT_AXIS_SEPARABLE_PACKED).
+# *_s201 force the axis-separable layout with full group blocks (bit-identical to the dense kernel, keeps the
+# reference's rounding-level asymmetry of P); *_full / *_packed force the dense kernel (what general matrices
+# get): full P, or symmetric-packed P (101 = 1 + TARGET_LAYOUT_SYMMETRIC_PACKED).
 TUNED_LANES = {"cfg2_full": 3, "uv1m_full": 1, "ua1m_full": 1, "ar1m_full": 6, "av1m_full": 3, "uv1m_packed": 101,
-               "uv1m_sp": 301, "ua1m_sp": 301, "av1m_sp": 301, "ar1m_sp": 301}
+               "uv1m_s201": 201, "ua1m_s201": 201, "av1m_s201": 201, "ar1m_s201": 201}
 
 WORKLOADS = {
     # name: (description, model, dtype, targets per GPU, seed)
@@ -49,10 +49,10 @@ WORKLOADS = {
     "ua1m_full": ("1000000 targets, uniform-acceleration model, fp32, dense kernel with full P", "uniform_acceleration", "f32", 1_000_000, 20240013),
     "ar1m_full": ("1000000 targets, angular-rates model, fp32, dense kernel with full P", "angular_rates", "f32", 1_000_000, 20240014),
     "av1m_full": ("1000000 targets, angular-velocities model, fp32, dense kernel with full P", "angular_velocities", "f32", 1_000_000, 20240015),
-    "uv1m_sp": ("1000000 targets, uniform-velocity model, fp64, separable + symmetric-packed groups", "uniform_velocity", "f64", 1_000_000, 20240012),
-    "ua1m_sp": ("1000000 targets, uniform-acceleration model, fp32, separable + symmetric-packed groups", "uniform_acceleration", "f32", 1_000_000, 20240013),
-    "av1m_sp": ("1000000 targets, angular-velocities model, fp32, separable + symmetric-packed groups", "angular_velocities", "f32", 1_000_000, 20240015),
-    "ar1m_sp": ("1000000 targets, angular-rates model, fp32, separable + symmetric-packed groups", "angular_rates", "f32", 1_000_000, 20240014),
+    "uv1m_s201": ("1000000 targets, uniform-velocity model, fp64, axis-separable layout with full group blocks", "uniform_velocity", "f64", 1_000_000, 20240012),
+    "ua1m_s201": ("1000000 targets, uniform-acceleration model, fp32, axis-separable layout with full group blocks", "uniform_acceleration", "f32", 1_000_000, 20240013),
+    "av1m_s201": ("1000000 targets, angular-velocities model, fp32, axis-separable layout with full group blocks", "angular_velocities", "f32", 1_000_000, 20240015),
+    "ar1m_s201": ("1000000 targets, angular-rates model, fp32, axis-separable layout with full group blocks", "angular_rates", "f32", 1_000_000, 20240014),
     "ar1m64": ("1000000 targets, angular-rates model, fp64", "angular_rates", "f64", 1_000_000, 20240016),
     "av1m64": ("1000000 targets, angular-velocities model, fp64", "angular_velocities", "f64", 1_000_000, 20240017),
 }
@@ -365,7 +365,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + sorted(MIXED))
     ap.add_argument("--lanes", type=int, default=0, help="lanes per target (0 = tuned default)")
     ap.add_argument("--targets", type=int, default=0, help="override targets per GPU")
-    ap.add_argument("--extra", default="cfg3,cfg4,cfg5,uv1m,ua1m,av1m,ar1m,ar1m_sp,av1m_sp,cfg2_full,uv1m_full,uv1m_packed,ar1m_full", help="comma list of extra workloads reported under 'extra' (N=1 only; '' = none)")
+    ap.add_argument("--extra", default="cfg3,cfg4,cfg5,uv1m,ua1m,av1m,ar1m,ar1m_s201,av1m_s201,cfg2_full,uv1m_full,uv1m_packed,ar1m_full", help="comma list of extra workloads reported under 'extra' (N=1 only; '' = none)")
     ap.add_argument("--extra-multi", default="uv1m,ua1m,av1m,ar1m,cfg4",
                     help="extra workloads when --gpus > 1 (per-GPU sizes; every rank runs them in lockstep)")
     ap.add_argument("--extra-steps", type=int, default=50)
@@ -411,7 +411,7 @@ def main():
                   ({"gather_pose_ms": res["gather_pose_ms"]} if "gather_pose_ms" in res else {}),
         "roofline": {"bound": "hbm", "achieved": res["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": res["achieved_gbs"] / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": ("kf_step_sep_kernel<%s,%s>" % (res["model"], res["dtype"]) if res["layout"] == "axis_separable"
+                     "kernel": ("kf_step_sep_kernel<%s,%s>" % (res["model"], res["dtype"]) if res["layout"].startswith("axis_separable")
                                 else "kf_step_kernel<%s,%s,G=%d,%s>" % (res["model"], res["dtype"], res["lanes_per_target"], res["layout"])),
                      "survey_full_P_bytes_per_cycle": (FULL_P_BYTES[res["model"]] * (8 if res["dtype"] == "f64" else 4)
                                                        if res["model"] in FULL_P_BYTES else None),

@@ -40,12 +40,15 @@ extern "C" {
 /* ---- construction ---------------------------------------------------------------------- */
 /* file may be NULL (no default model: use the *_typed initialisers, as the reference's
  * default-constructed TargetManager, target_manager.cpp:106-109).  dtype: TARGET_DTYPE_*.
- * lanes_per_target: 0 = automatic: the axis-separable layout when the matrices allow it (checked per
- * init call; see TARGET_LAYOUT_AXIS_SEPARABLE), else the tuned dense default for (model, dtype);
- * otherwise 1, 2, 3 or 6 (dense, full P), 1 + TARGET_LAYOUT_AXIS_SEPARABLE, or
- * 1 + TARGET_LAYOUT_SYMMETRIC_PACKED (thread per target, upper triangle of P only in HBM: 45 % less
- * traffic; P is then symmetric by construction, whereas the reference's (I-KC)P is symmetric only to
- * rounding). */
+ * lanes_per_target: 0 = automatic, checked per init call: when Q, R and P0 do not couple different axis
+ * groups, the axis-separable layout -- with each group block stored as its upper triangle
+ * (1 + TARGET_LAYOUT_AXIS_SEPARABLE_PACKED) when the matrices are also exactly symmetric, with full
+ * group blocks (1 + TARGET_LAYOUT_AXIS_SEPARABLE) otherwise -- else the tuned dense default for
+ * (model, dtype).  Explicit: 1, 2, 3 or 6 (dense, full P), 1 + TARGET_LAYOUT_SYMMETRIC_PACKED (dense,
+ * thread per target, upper triangle of P only in HBM: 45 % less traffic), or one of the two separable
+ * codes.  With a packed layout P is symmetric by construction, whereas the reference's (I-KC)P is
+ * symmetric only to rounding; the full layouts reproduce that rounding-level asymmetry (the
+ * axis-separable full-block layout is bit-identical to the dense kernel). */
 target_manager_c* target_manager_new_ex(const char* file, int dtype, int lanes_per_target);
 /* all launches of this manager go to `hip_stream` (a hipStream_t; NULL = default stream) */
 int target_manager_set_stream(target_manager_c* self, void* hip_stream);

@@ -101,11 +101,29 @@ bool is_axis_separable(int type, const double* Q, const double* R, const double*
   return true;
 }
 
+// exact symmetry of Q, R and every P0 (covariances are; the reference accepts any matrix)
+static bool all_symmetric(int type, const double* Q, const double* R, const double* P0, long n_P0) {
+  const int n = model_n(type), m = model_m(type);
+  for (int r = 0; r < n; ++r)
+    for (int c = r + 1; c < n; ++c) {
+      if (Q[r * n + c] != Q[c * n + r]) return false;
+      for (long k = 0; k < n_P0; ++k)
+        if (P0[k * n * n + r * n + c] != P0[k * n * n + c * n + r]) return false;
+    }
+  for (int r = 0; r < m; ++r)
+    for (int c = r + 1; c < m; ++c)
+      if (R[r * m + c] != R[c * m + r]) return false;
+  return true;
+}
+
 int TargetManager::chooseLayout(int type, const double* Q, const double* R, const double* P0, long n_P0) const {
-  constexpr int kSeparable = 201;  // 1 + TARGET_LAYOUT_AXIS_SEPARABLE
+  constexpr int kSeparable = 201;        // 1 + TARGET_LAYOUT_AXIS_SEPARABLE
+  constexpr int kSeparablePacked = 301;  // 1 + TARGET_LAYOUT_AXIS_SEPARABLE_PACKED
   const bool sep = is_axis_separable(type, Q, R, P0, n_P0);
-  if (lanes_ == 0) return sep ? kSeparable : 0;
-  if ((lanes_ == kSeparable || lanes_ == kSeparable + 100) && !sep)
+  // automatic: the smallest record the matrices allow -- per-axis-group blocks when nothing couples the
+  // groups, their upper triangles only when everything is symmetric as well
+  if (lanes_ == 0) return !sep ? 0 : (all_symmetric(type, Q, R, P0, n_P0) ? kSeparablePacked : kSeparable);
+  if ((lanes_ == kSeparable || lanes_ == kSeparablePacked) && !sep)
     throw std::runtime_error("target_estimation_amd: the axis-separable layout was requested but Q, R or P0 couple different axes");
   return lanes_;
 }

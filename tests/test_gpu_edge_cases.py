@@ -200,7 +200,7 @@ def test_reference_harness_in_fp32(models, harness_stream, name):
     mgr.close()
 
 
-@pytest.mark.parametrize("wl", ["ar1m", "uv1m", "ar1m_full", "av1m_sp"])
+@pytest.mark.parametrize("wl", ["ar1m", "uv1m", "ar1m_full", "av1m_s201"])
 def test_full_size_properties(models, wl):
     """BASELINE-size batches (10^6 targets): properties that do not need the oracle on every target
     (finite, covariance symmetric to rounding with positive diagonal, slot ids in order, predict-only

@@ -28,7 +28,7 @@ LANES = {"uniform_velocity": {"f64": [0, 1, 3, 101, 201, 301], "f32": [1, 3, 101
          "uniform_acceleration": {"f64": [0, 1, 3, 101, 201, 301], "f32": [1, 3, 101, 201, 301]},
          "angular_rates": {"f64": [0, 3, 6, 201, 301], "f32": [2, 3, 6, 201, 301]},
          "angular_velocities": {"f64": [0, 3, 6, 201, 301], "f32": [1, 3, 6, 101, 201, 301]}}
-LAYOUT_OF = {0: "axis_separable", 101: "symmetric_packed", 201: "axis_separable", 301: "axis_separable_packed"}
+LAYOUT_OF = {0: "axis_separable_packed", 101: "symmetric_packed", 201: "axis_separable", 301: "axis_separable_packed"}
 CASES = [(m, d, g) for m in HARNESS_ORDER for d in ("f64", "f32") for g in LANES[m][d]]
 
 
@@ -141,6 +141,31 @@ def test_general_matrices_use_the_dense_kernel(models, name, dtype):
     with pytest.raises(RuntimeError, match="couple different axes"):
         sep.init_batch(ids, dt, 0.0, p0, type=m["model"], Q=cm["Q"], R=cm["R"], P0=cm["P"])
     sep.close()
+
+
+@pytest.mark.parametrize("name", ["uniform_acceleration", "angular_velocities"])
+def test_automatic_layout_follows_the_matrices(models, name):
+    """Shipped (symmetric, axis-separable) matrices -> packed group blocks; a P0 that is separable but not
+    symmetric -> full group blocks (nothing may be dropped); parity with the oracle in both cases."""
+    m = models[name]
+    N, steps, dt = 100, 30, 0.004
+    p0, meas = synth_stream(name, N, steps, seed=19)
+    ids = np.arange(N, dtype=np.uint32)
+    P_asym = m["P"].copy()
+    j = 3 if name == "uniform_acceleration" else 6                    # x and its rate: same axis group
+    P_asym[0, j] = 0.25 * np.sqrt(P_asym[0, 0] * P_asym[j, j])       # ... coupled on one side only
+    for P0, want in ((m["P"], "axis_separable_packed"), (P_asym, "axis_separable")):
+        mgr = te.TargetManager(dtype="f64")
+        mgr.init_batch(ids, dt, 0.0, p0, type=m["model"], Q=m["Q"], R=m["R"], P0=P0)
+        b = mgr.batches()[0]
+        assert b.layout == want
+        orc = oracle.OracleBatch(m["model"], m["Q"], m["R"], P0, p0, dt, dtype="f64")
+        check_state(mgr, ids, orc, "f64", "%s init" % want)
+        for s in range(steps):
+            b.step(dt, to_soa(meas[s], b))
+            orc.step(dt, meas[s])
+        check_state(mgr, ids, orc, "f64", want)
+        mgr.close()
 
 
 @pytest.mark.parametrize("name", HARNESS_ORDER)
