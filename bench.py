@@ -366,7 +366,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="lanes per target (0 = tuned default)")
     ap.add_argument("--targets", type=int, default=0, help="override targets per GPU")
     ap.add_argument("--extra", default="cfg3,cfg4,cfg5,uv1m,ua1m,av1m,ar1m,ar1m_s201,av1m_s201,cfg2_full,uv1m_full,uv1m_packed,ar1m_full", help="comma list of extra workloads reported under 'extra' (N=1 only; '' = none)")
-    ap.add_argument("--extra-multi", default="uv1m,ua1m,av1m,ar1m,cfg4",
+    ap.add_argument("--extra-multi", default="uv1m,ua1m,av1m,ar1m,cfg4,cfg5",
                     help="extra workloads when --gpus > 1 (per-GPU sizes; every rank runs them in lockstep)")
     ap.add_argument("--extra-steps", type=int, default=50)
     ap.add_argument("--no-cpu", action="store_true")
