@@ -45,6 +45,8 @@ Batch::~Batch() {
   (void)hipFree(d_idx_); (void)hipFree(d_aos_); (void)hipFree(d_meas_); (void)hipFree(d_mask_); (void)hipFree(d_P0_);
   (void)hipFree(d_gate_ring_); (void)hipFree(d_gate_sum_); (void)hipFree(d_gate_state_); (void)hipFree(d_gate_prev_);
   (void)hipFree(d_dtper_);
+  if (h_pin_) (void)hipHostFree(h_pin_);
+  if (h_cache_) (void)hipHostFree(h_cache_);
 }
 
 bool Batch::same_params(int type, const double* Q, const double* R) const {
@@ -311,40 +313,71 @@ void Batch::step_one(long slot, double dt, const double* meas7) {
   for (int c = 0; c < 7; ++c) p.meas[c] = meas7 ? meas7[c] : 0.0;
   pending_.push_back(p);
   pending_mark_[(size_t)slot] = 1;
+}
+
+void Batch::pin_reserve(long k) {
+  if (k <= pin_cap_) return;
+  const long want = (std::max<long>(std::max<long>(k, 64), pin_cap_ * 2) + 15) / 16 * 16;   // keeps the sections aligned
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));
+  if (h_pin_) (void)hipHostFree(h_pin_);
+  h_pin_ = nullptr; d_pin_ = nullptr; pin_cap_ = 0;
+  const size_t bytes = (size_t)want * (sizeof(int) + sizeof(double) + 7 * elem_size() + 1) + 64;
+  TE_HIP_CHECK(hipHostMalloc((void**)&h_pin_, bytes, hipHostMallocMapped));
+  TE_HIP_CHECK(hipHostGetDevicePointer((void**)&d_pin_, h_pin_, 0));
+  pin_cap_ = want;
+}
+
+void Batch::cache_reserve(long n) {
+  if (n <= cache_cap_) return;
+  const long want = std::max<long>(std::max<long>(n, 64), std::min<long>(cache_cap_ * 2, kCacheMax));
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));
+  if (h_cache_) (void)hipHostFree(h_cache_);
+  h_cache_ = nullptr; d_cache_ = nullptr; cache_cap_ = 0;
+  TE_HIP_CHECK(hipHostMalloc((void**)&h_cache_, sizeof(double) * 19 * (size_t)want, hipHostMallocMapped));
+  TE_HIP_CHECK(hipHostGetDevicePointer((void**)&d_cache_, h_cache_, 0));
+  cache_cap_ = want;
   cache_valid_ = false;
 }
 
 void Batch::flush() {
   const long k = (long)pending_.size();
   if (!k) return;
-  std::vector<int> slots((size_t)k);
-  std::vector<double> dts((size_t)k), meas((size_t)k * 7);
-  std::vector<unsigned char> has((size_t)k);
+  pin_reserve(k);
+  // sections of the pinned block (sized by its capacity, so that the offsets are 8-byte aligned)
+  const size_t es = elem_size();
+  const size_t off_dt = (size_t)pin_cap_ * sizeof(int), off_meas = off_dt + (size_t)pin_cap_ * sizeof(double),
+               off_has = off_meas + (size_t)pin_cap_ * 7 * es;
+  int* h_idx = reinterpret_cast<int*>(h_pin_);
+  double* h_dt = reinterpret_cast<double*>(h_pin_ + off_dt);
+  unsigned char* h_has = reinterpret_cast<unsigned char*>(h_pin_ + off_has);
   bool all_has = true, any_has = false;
   for (long j = 0; j < k; ++j) {
     const Pending& p = pending_[(size_t)j];
-    slots[(size_t)j] = p.slot; dts[(size_t)j] = p.dt; has[(size_t)j] = p.has;
-    for (int c = 0; c < 7; ++c) meas[(size_t)j * 7 + c] = p.meas[c];
+    h_idx[j] = p.slot; h_dt[j] = p.dt; h_has[j] = p.has;
+    // SoA [7][k] in the batch precision (what pack_meas produces on the device)
+    if (dtype_ == F64) { double* m = reinterpret_cast<double*>(h_pin_ + off_meas); for (int c = 0; c < 7; ++c) m[(size_t)c * k + j] = p.meas[c]; }
+    else { float* m = reinterpret_cast<float*>(h_pin_ + off_meas); for (int c = 0; c < 7; ++c) m[(size_t)c * k + j] = (float)p.meas[c]; }
     all_has = all_has && p.has;
     any_has = any_has || p.has;
     pending_mark_[(size_t)p.slot] = 0;
   }
   pending_.clear();
-  stage_reserve(k);
-  upload_slots(slots.data(), k);
-  TE_HIP_CHECK(hipMemcpyAsync(d_dtper_, dts.data(), sizeof(double) * k, hipMemcpyHostToDevice, stream_));
-  if (any_has) {
-    TE_HIP_CHECK(hipMemcpyAsync(d_aos_, meas.data(), sizeof(double) * 7 * k, hipMemcpyHostToDevice, stream_));
-    ops_->pack_meas(d_aos_, k, d_meas_, k, stream_);
-    if (!all_has) TE_HIP_CHECK(hipMemcpyAsync(d_mask_, has.data(), (size_t)k, hipMemcpyHostToDevice, stream_));
-  }
   StepParams p;
-  p.rec = d_rec_; p.qr = d_qr_; p.n = k; p.idx = d_idx_; p.meas = any_has ? d_meas_ : nullptr; p.meas_ld = k;
-  p.has_meas = (any_has && !all_has) ? d_mask_ : nullptr; p.dt_per = d_dtper_; p.dt = 0.0;
+  p.rec = d_rec_; p.qr = d_qr_; p.n = k; p.idx = reinterpret_cast<const int*>(d_pin_);
+  p.meas = any_has ? d_pin_ + off_meas : nullptr; p.meas_ld = k;
+  p.has_meas = (any_has && !all_has) ? reinterpret_cast<const unsigned char*>(d_pin_ + off_has) : nullptr;
+  p.dt_per = reinterpret_cast<const double*>(d_pin_ + off_dt); p.dt = 0.0;
   p.t_base = d_tbase_; p.nm_base = d_nmbase_;
   ops_->step(p, stream_);
+  if (cache_valid_) {   // keep the getter table current: only the stepped slots change
+    OutArgs a;
+    a.rec = d_rec_; a.idx = p.idx; a.n = k; a.by_slot = 1;
+    a.pose = d_cache_; a.twist = d_cache_ + 7 * n_; a.acc = d_cache_ + 13 * n_;
+    a.at_time = 0; a.t1 = 0.0; a.t_acc = t_acc_; a.t_base = d_tbase_;
+    ops_->outputs(a, stream_);
+  }
   TE_HIP_CHECK(hipGetLastError());
-  TE_HIP_CHECK(hipStreamSynchronize(stream_));   // the staging vectors above go out of scope
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));   // the pinned block is rewritten by the next flush
 }
 
 void Batch::outputs(const int* slots, long n, double* pose, double* twist, double* acc, bool at_time, double t1) {
@@ -381,15 +414,22 @@ void Batch::outputs_one(long slot, double* pose, double* twist, double* acc, boo
     outputs(&one, 1, pose, twist, acc, at_time, t1);
     return;
   }
-  // small batch (the reference's scale): one kernel + one copy serve every getter until the next step
+  // small batch (the reference's scale): a host-resident table of every slot's outputs, written by the
+  // kernels themselves; filled once, then kept current by flush()
   if (!cache_valid_) {
-    cache_out_.resize((size_t)n_ * 19);
-    outputs(nullptr, n_, cache_out_.data(), cache_out_.data() + 7 * n_, cache_out_.data() + 13 * n_, false, 0.0);
+    cache_reserve(n_);
+    OutArgs a;
+    a.rec = d_rec_; a.idx = nullptr; a.n = n_;
+    a.pose = d_cache_; a.twist = d_cache_ + 7 * n_; a.acc = d_cache_ + 13 * n_;
+    a.at_time = 0; a.t1 = 0.0; a.t_acc = t_acc_; a.t_base = d_tbase_;
+    ops_->outputs(a, stream_);
+    TE_HIP_CHECK(hipGetLastError());
+    TE_HIP_CHECK(hipStreamSynchronize(stream_));
     cache_valid_ = true;
   }
-  if (pose) std::memcpy(pose, &cache_out_[(size_t)slot * 7], sizeof(double) * 7);
-  if (twist) std::memcpy(twist, &cache_out_[(size_t)n_ * 7 + (size_t)slot * 6], sizeof(double) * 6);
-  if (acc) std::memcpy(acc, &cache_out_[(size_t)n_ * 13 + (size_t)slot * 6], sizeof(double) * 6);
+  if (pose) std::memcpy(pose, h_cache_ + (size_t)slot * 7, sizeof(double) * 7);
+  if (twist) std::memcpy(twist, h_cache_ + (size_t)n_ * 7 + (size_t)slot * 6, sizeof(double) * 6);
+  if (acc) std::memcpy(acc, h_cache_ + (size_t)n_ * 13 + (size_t)slot * 6, sizeof(double) * 6);
 }
 
 void Batch::intersect(const int* slots, long n, double t1, const double* origin, double radius, double* delta, double* pose) {

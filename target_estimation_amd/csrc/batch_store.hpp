@@ -170,8 +170,17 @@ class Batch {
   std::vector<Pending> pending_;
   std::vector<unsigned char> pending_mark_;
   double* d_dtper_ = nullptr;
-  static constexpr long kCacheMax = 16384;   // batches up to this size cache all outputs per flush
-  std::vector<double> cache_out_;            // [n][19]: pose7 | twist6 | acc6
+  // Both live in pinned, device-mapped host memory: the kernels read the queued inputs and write the
+  // outputs there directly, so a flush is two launches and one stream synchronisation, no copies.
+  void pin_reserve(long k);
+  char* h_pin_ = nullptr;                    // idx int[cap] | dt double[cap] | meas T[7][cap] | has uchar[cap]
+  char* d_pin_ = nullptr;                    // the same memory as the device sees it
+  long pin_cap_ = 0;
+  static constexpr long kCacheMax = 16384;   // batches up to this size keep every slot's outputs on the host
+  void cache_reserve(long n);
+  double* h_cache_ = nullptr;                // [n][7] pose | [n][6] twist | [n][6] acceleration
+  double* d_cache_ = nullptr;
+  long cache_cap_ = 0;
   bool cache_valid_ = false;
   void touch() { flush(); cache_valid_ = false; }   // call before anything that changes state
 };

@@ -177,6 +177,7 @@ struct OutArgs {
   double t1;        // absolute query time (at_time); NaN = each target's own time
   double t_acc;     // batch clock; target time = t_base[slot] + t_acc
   const double* t_base;
+  int by_slot = 0;  // 1: output row = slot (scatter into a per-slot table) instead of the entry index
 };
 
 // Derived outputs of one target, from x only.
@@ -269,9 +270,10 @@ __global__ void outputs_kernel(const OutArgs a) {
   if (a.at_time) d = (a.t1 != a.t1) ? (T)0 : (T)(a.t1 - (a.t_base[slot] + a.t_acc));
   T pose7[7], twist6[6], acc6[6];
   derive_outputs<M, T>(x, a.at_time != 0, d, pose7, twist6, acc6);
-  if (a.pose) for (int c = 0; c < 7; ++c) a.pose[e * 7 + c] = (double)pose7[c];
-  if (a.twist) for (int c = 0; c < 6; ++c) a.twist[e * 6 + c] = (double)twist6[c];
-  if (a.acc) for (int c = 0; c < 6; ++c) a.acc[e * 6 + c] = (double)acc6[c];
+  const long row = a.by_slot ? slot : e;
+  if (a.pose) for (int c = 0; c < 7; ++c) a.pose[row * 7 + c] = (double)pose7[c];
+  if (a.twist) for (int c = 0; c < 6; ++c) a.twist[row * 6 + c] = (double)twist6[c];
+  if (a.acc) for (int c = 0; c < 6; ++c) a.acc[row * 6 + c] = (double)acc6[c];
 }
 
 struct IntersectArgs {
