@@ -313,3 +313,47 @@ def _one(orc, i, dt, meas_row):
     else:
         row = np.ascontiguousarray(meas_row, dtype=np.float64)
         orc._f("orc_target_add_measurement")(orc._at(i), float(dt), row.ctypes.data_as(C.POINTER(C.c_double)))
+
+
+@pytest.mark.parametrize("name,dtype", [("uniform_acceleration", "f64"), ("angular_rates", "f32"), ("angular_velocities", "f64")])
+def test_getter_table_stays_current(models, name, dtype):
+    """The one-target getters are served from a host table that a flush updates only for the stepped slots:
+    after any mix of one-target steps, batch steps, erase (slots move) and re-creation every scalar getter
+    must equal the batch getter, which always runs the outputs kernel on the device."""
+    rng = np.random.default_rng(21)
+    N, dt = 37, 0.004
+    p0, meas = synth_stream(name, N, 40, seed=23)
+    ids = list(range(100, 100 + N))
+    mgr = te.TargetManager(model_path(name), dtype=dtype)
+    mgr.init_batch(np.array(ids, dtype=np.uint32), dt, 0.0, p0)
+
+    def check():
+        arr = np.array(ids, dtype=np.uint32)
+        pose, twist, acc, found = mgr.get_est_batch(arr)
+        assert found.all()
+        for j in rng.permutation(len(ids))[:12]:
+            for getter, want in ((mgr.getTargetPose, pose), (mgr.getTargetTwist, twist), (mgr.getTargetAcceleration, acc)):
+                ok, got = getter(ids[j])
+                assert ok
+                np.testing.assert_array_equal(got, want[j])
+
+    check()                                               # fills the table
+    for s in range(30):
+        op = s % 6
+        if op in (0, 1, 2):                               # a few one-target steps, read back at once / later
+            for j in rng.choice(len(ids), size=3, replace=False):
+                mgr.update(ids[j], dt, meas[s][j % N] if rng.random() < 0.8 else None)
+                if op == 0:
+                    mgr.getTargetPose(ids[j])             # flush per target (the reference test's loop)
+        elif op == 3:                                     # by-id batch step of a subset
+            sub = rng.permutation(len(ids))[:10]
+            mgr.update_batch(np.array([ids[j] for j in sub], dtype=np.uint32), dt, meas[s][[j % N for j in sub]])
+        elif op == 4:                                     # erase: the last slot moves into the hole
+            victim = ids.pop(int(rng.integers(len(ids) - 1)))
+            assert mgr.erase(victim)
+        else:                                             # a new target appears
+            new_id = 1000 + s
+            mgr.init(new_id, dt, s * dt, p0[s % N])
+            ids.append(new_id)
+        check()
+    mgr.close()
