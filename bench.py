@@ -146,7 +146,7 @@ def run_mixed(te, torch, name, steps, warmup, dist=None, rank=0, world=1, stream
     n_total = sum(b.size for b in batches)
     alg = sum(b.algorithmic_bytes * b.size for b in batches)
     if intersect:
-        alg += sum((b.state_dim + 1 + 8) * 8 * b.size for b in batches)   # query: read x (+t), write delta + pose7 (doubles out)
+        alg += sum(8 * 8 * b.size for b in batches)   # query: writes delta + pose7 (doubles); its input is the step's state
     for b in batches:
         p, _, _ = b.get_est(twist=False, acc=False)
         assert torch.isfinite(p).all()

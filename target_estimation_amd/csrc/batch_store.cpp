@@ -230,27 +230,27 @@ void Batch::step_sequence(long n_ticks, double dt, const void* meas_base, long t
   if (meas_base && !has_base) nm_acc_ += n_ticks;
 }
 
-void Batch::enqueue_sequence(hipStream_t st, long n_ticks, double dt, const SeqSpec& q, bool query, const double* origin,
-                             double radius) {
+void Batch::enqueue_tick(hipStream_t st, long s, double dt, const SeqSpec& q, bool query, const double* origin, double radius) {
   if (n_ == 0) return;
   const size_t es = elem_size();
-  for (long s = 0; s < n_ticks; ++s) {
-    StepParams p;
-    p.rec = d_rec_; p.qr = d_qr_; p.n = n_; p.idx = nullptr;
-    p.meas = q.meas_base ? static_cast<const char*>(q.meas_base) + (size_t)(s * q.tick_stride) * es : nullptr;
-    p.meas_ld = q.ld;
-    p.has_meas = q.has_base ? q.has_base + s * q.has_stride : nullptr;
-    p.dt_per = nullptr; p.dt = dt; p.t_base = d_tbase_; p.nm_base = d_nmbase_;
-    ops_->step(p, st);
-    if (query) {
-      IntersectArgs a;
-      a.rec = d_rec_; a.idx = nullptr; a.n = n_; a.t1 = std::numeric_limits<double>::quiet_NaN();
-      a.origin[0] = origin[0]; a.origin[1] = origin[1]; a.origin[2] = origin[2]; a.radius = radius;
-      a.t_acc = 0.0; a.t_base = d_tbase_; a.delta = q.delta_dev; a.pose = q.pose_dev;
-      ops_->intersect(a, st);
-    }
+  StepParams p;
+  p.rec = d_rec_; p.qr = d_qr_; p.n = n_; p.idx = nullptr;
+  p.meas = q.meas_base ? static_cast<const char*>(q.meas_base) + (size_t)(s * q.tick_stride) * es : nullptr;
+  p.meas_ld = q.ld;
+  p.has_meas = q.has_base ? q.has_base + s * q.has_stride : nullptr;
+  p.dt_per = nullptr; p.dt = dt; p.t_base = d_tbase_; p.nm_base = d_nmbase_;
+  if (query && ops_->fused_query) {
+    p.q_origin[0] = origin[0]; p.q_origin[1] = origin[1]; p.q_origin[2] = origin[2];
+    p.q_radius = radius; p.q_delta = q.delta_dev; p.q_pose = q.pose_dev;
   }
-  TE_HIP_CHECK(hipGetLastError());
+  ops_->step(p, st);
+  if (query && !ops_->fused_query) {
+    IntersectArgs a;
+    a.rec = d_rec_; a.idx = nullptr; a.n = n_; a.t1 = std::numeric_limits<double>::quiet_NaN();
+    a.origin[0] = origin[0]; a.origin[1] = origin[1]; a.origin[2] = origin[2]; a.radius = radius;
+    a.t_acc = 0.0; a.t_base = d_tbase_; a.delta = q.delta_dev; a.pose = q.pose_dev;
+    ops_->intersect(a, st);
+  }
 }
 
 void Batch::account_sequence(long n_ticks, double dt, bool all_measured) {

@@ -290,8 +290,36 @@ struct IntersectArgs {
 };
 
 // IntersectionSolver::getIntersectionTimeWithSphere / getIntersectionPoseWithSphere without the
-// moving-average convergence gate (src/intersection_solver.cpp:42-104): quartic in delta from the
-// extrapolated (p, v, a) at t1, smallest real root, pose at t1 + delta.
+// moving-average convergence gate (src/intersection_solver.cpp:42-104) for one target with state x:
+// quartic in delta from the (p, v, a) extrapolated by dq = t1 - t_, smallest real root, pose at
+// t1 + delta.  own = the query is at the target's own time (dq = 0, pose offset = delta itself).
+template <class M, typename T>
+__device__ __forceinline__ void sphere_query(const T* x, bool own, double t1, double t, const double* origin, double radius,
+                                             double* delta_out, double* pose_out /* [7] or null */) {
+  T pose7[7], twist6[6], acc6[6];
+  derive_outputs<M, T>(x, true, own ? (T)0 : (T)(t1 - t), pose7, twist6, acc6);
+  const double px = (double)pose7[0] - origin[0], py = (double)pose7[1] - origin[1], pz = (double)pose7[2] - origin[2];
+  const double vx = (double)twist6[0], vy = (double)twist6[1], vz = (double)twist6[2];
+  const double ax = (double)acc6[0], ay = (double)acc6[1], az = (double)acc6[2];
+  double c[5];
+  c[4] = 0.25 * (ax * ax + ay * ay + az * az);
+  c[3] = vx * ax + vy * ay + vz * az;
+  c[2] = vx * vx + vy * vy + vz * vz + px * ax + py * ay + pz * az;
+  c[1] = 2 * (px * vx + py * vy + pz * vz);
+  c[0] = px * px + py * py + pz * pz - radius * radius;
+  const double d = first_crossing_quartic(c);   // leftmost real root if >= 0, else -1
+  *delta_out = d;
+  if (pose_out) {
+    double out[7] = {0, 0, 0, 0, 0, 0, 1};
+    if (d > -1) {
+      derive_outputs<M, T>(x, true, own ? (T)d : (T)((d + t1) - t), pose7, twist6, acc6);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) out[k] = (double)pose7[k];
+    }
+    for (int k = 0; k < 7; ++k) pose_out[k] = out[k];
+  }
+}
+
 template <class M, typename T, int G, int LAYOUT>
 __global__ void intersect_kernel(const IntersectArgs a) {
   using C = Cfg<M, T, G, LAYOUT>;
@@ -306,29 +334,7 @@ __global__ void intersect_kernel(const IntersectArgs a) {
   // does not depend on the batch clock; the reference's (delta + t1) - t_ differs by at most ulp(t_)
   const bool own = a.t1 != a.t1;
   const double t = own ? 0.0 : a.t_base[slot] + a.t_acc;
-  const double t1 = own ? 0.0 : a.t1;
-  T pose7[7], twist6[6], acc6[6];
-  derive_outputs<M, T>(x, true, (T)(t1 - t), pose7, twist6, acc6);
-  const double px = (double)pose7[0] - a.origin[0], py = (double)pose7[1] - a.origin[1], pz = (double)pose7[2] - a.origin[2];
-  const double vx = (double)twist6[0], vy = (double)twist6[1], vz = (double)twist6[2];
-  const double ax = (double)acc6[0], ay = (double)acc6[1], az = (double)acc6[2];
-  double c[5];
-  c[4] = 0.25 * (ax * ax + ay * ay + az * az);
-  c[3] = vx * ax + vy * ay + vz * az;
-  c[2] = vx * vx + vy * vy + vz * vz + px * ax + py * ay + pz * az;
-  c[1] = 2 * (px * vx + py * vy + pz * vz);
-  c[0] = px * px + py * py + pz * pz - a.radius * a.radius;
-  const double d = first_crossing_quartic(c);   // leftmost real root if >= 0, else -1
-  a.delta[e] = d;
-  if (a.pose) {
-    double out[7] = {0, 0, 0, 0, 0, 0, 1};
-    if (d > -1) {
-      derive_outputs<M, T>(x, true, (T)((d + t1) - t), pose7, twist6, acc6);
-#pragma unroll
-      for (int k = 0; k < 7; ++k) out[k] = (double)pose7[k];
-    }
-    for (int k = 0; k < 7; ++k) a.pose[e * 7 + k] = out[k];
-  }
+  sphere_query<M, T>(x, own, a.t1, t, a.origin, a.radius, &a.delta[e], a.pose ? &a.pose[e * 7] : nullptr);
 }
 
 }  // namespace te

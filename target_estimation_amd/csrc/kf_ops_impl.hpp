@@ -21,6 +21,10 @@ struct OpsImpl {
     a.meas = static_cast<const T*>(p.meas); a.meas_ld = p.meas_ld; a.has_meas = p.has_meas;
     a.dt_per = p.dt_per; a.dt = p.dt; a.t_base = p.t_base; a.nm_base = p.nm_base;
     a.n_ticks = p.n_ticks; a.tick_stride = p.tick_stride; a.has_stride = p.has_stride;
+    a.q_origin[0] = p.q_origin[0]; a.q_origin[1] = p.q_origin[1]; a.q_origin[2] = p.q_origin[2];
+    a.q_radius = p.q_radius; a.q_delta = p.q_delta; a.q_pose = p.q_pose;
+    if (p.q_delta && (!C::SEP || p.idx || p.n_ticks > 1))
+      throw std::runtime_error("target_estimation_amd: the fused query needs a separable layout and a dense single-tick launch");
     const long waves = (p.n + C::TPW - 1) / C::TPW;
     static const long small_grid = [] { const char* e = std::getenv("TE_SMALL_GRID_WAVES"); return e ? std::atol(e) : 1024L; }();
     // small (latency-bound) grids: one wavefront per workgroup spreads the waves over more CUs
@@ -36,6 +40,8 @@ struct OpsImpl {
         hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, false, true>), dim3(b4), blk, 0, s, a);
       else if (p.idx)
         hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, true>), dim3(b4), blk, 0, s, a);
+      else if (p.q_delta)
+        hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, false, false, true>), dim3(b4), blk, 0, s, a);
       else
         hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, false>), dim3(b4), blk, 0, s, a);
     } else {
@@ -80,7 +86,7 @@ struct OpsImpl {
   static const Ops* get() {
     static const Ops ops = {
         LayoutInfo{C::N, C::K, G, LAYOUT, C::TPW, C::LPT, C::RW, C::TILE_BYTES, C::TILE_PAYLOAD},
-        C::WPB, &step, &init, &get_state, &set_state, &move_record, &outputs, &pack_meas, &intersect};
+        C::WPB, C::SEP, &step, &init, &get_state, &set_state, &move_record, &outputs, &pack_meas, &intersect};
     return &ops;
   }
 };

@@ -46,6 +46,12 @@ struct StepArgs {
   int n_ticks;
   long tick_stride;
   long has_stride;
+  // fused own-time sphere query after the step (QUERY variants of the separable kernel only):
+  // q_delta [n], q_pose [n][7] or null (device doubles)
+  double q_origin[3];
+  double q_radius;
+  double* q_delta;
+  double* q_pose;
 };
 
 template <typename T> struct Vec16;

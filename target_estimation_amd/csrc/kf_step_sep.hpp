@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "kf_aux.hpp"
 #include "kf_step.hpp"
 
 namespace te {
@@ -74,8 +75,12 @@ __device__ __forceinline__ void sep_linear_axis(T* x, T (&P)[NB][NB], const T (&
   }
 }
 
-template <class M, typename T, int LAYOUT, bool INDEXED, bool FUSED = false>
+// QUERY: the own-time sphere-intersection query of the target (kf_aux.hpp, sphere_query) runs on the
+// posterior state while it is still in registers -- BASELINE.json configs[4], "per-step interception
+// point fused on-GPU": one launch per tick instead of step + query.
+template <class M, typename T, int LAYOUT, bool INDEXED, bool FUSED = false, bool QUERY = false>
 __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
+  static_assert(!(QUERY && (INDEXED || FUSED)), "the fused query is for dense single-tick launches");
   using C = Cfg<M, T, 1, LAYOUT>;
   static_assert(C::SEP, "separable layouts only");
   constexpr int N = C::N, K = C::K, NB = C::NB, TPW = C::TPW;
@@ -320,6 +325,12 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
   }  // tick loop
   if (valid) {
     store_record<C, T>(tb, lt, mem);
+    if constexpr (QUERY) {
+      T xq[N];
+#pragma unroll
+      for (int r = 0; r < N; ++r) xq[r] = XW_(r);
+      sphere_query<M, T>(xq, true, 0.0, 0.0, a.q_origin, a.q_radius, &a.q_delta[entry], a.q_pose ? &a.q_pose[entry * 7] : nullptr);
+    }
     if constexpr (INDEXED) {
       const long slot = a.idx[entry];
       a.t_base[slot] += dtd * n_ticks;

@@ -662,12 +662,9 @@ void TargetManager::stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpe
   if (!use_graph) {
     for (long s = 0; s < n_ticks; ++s)
       for (size_t b = 0; b < nb; ++b) {
-        Batch::SeqSpec one = specs[b];
-        const size_t es = batches_[b]->elem_size();
-        if (one.meas_base) one.meas_base = static_cast<const char*>(one.meas_base) + (size_t)(s * one.tick_stride) * es;
-        if (one.has_base) one.has_base += s * one.has_stride;
-        batches_[b]->enqueue_sequence(stream_, 1, dt, one, query, org, radius);
+        batches_[b]->enqueue_tick(stream_, s, dt, specs[b], query, org, radius);
       }
+    TE_HIP_CHECK(hipGetLastError());
   } else {
     auto same_spec = [](const Batch::SeqSpec& x, const Batch::SeqSpec& y) {
       return x.meas_base == y.meas_base && x.tick_stride == y.tick_stride && x.ld == y.ld && x.has_base == y.has_base &&
@@ -686,13 +683,9 @@ void TargetManager::stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpe
     }
     if (!hit) {
       if (seq_graphs_.size() >= 8) dropSeqGraphs();
-      while (branch_streams_.size() < nb) {
+      if (branch_streams_.empty()) {
         hipStream_t st; TE_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         branch_streams_.push_back(st);
-      }
-      while (branch_events_.size() < nb + 1) {
-        hipEvent_t ev; TE_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        branch_events_.push_back(ev);
       }
       SeqGraph g;
       g.n_ticks = n_ticks; g.dt = dt; g.query = query; g.radius = radius;
@@ -700,23 +693,38 @@ void TargetManager::stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpe
       g.specs.assign(specs, specs + nb);
       for (size_t b = 0; b < nb; ++b) g.ident.push_back(batches_[b]->dev_identity());
       g.graph = nullptr; g.exec = nullptr;
-      hipStream_t root = branch_streams_[0];
-      TE_HIP_CHECK(hipStreamBeginCapture(root, hipStreamCaptureModeThreadLocal));
+      // The launches are captured on ONE stream whose dependency set is replaced at the head of every
+      // batch's chain (hipStreamUpdateCaptureDependencies): the chains become the branches of the graph.
+      hipStream_t cap = branch_streams_[0];
+      using Nodes = std::vector<hipGraphNode_t>;
+      auto set_deps = [&](Nodes& deps) {
+        TE_HIP_CHECK(hipStreamUpdateCaptureDependencies(cap, deps.empty() ? nullptr : deps.data(), deps.size(), hipStreamSetCaptureDependencies));
+      };
+      auto captured = [&]() {   // the node(s) the next launch would depend on = what was just captured
+        hipStreamCaptureStatus status; unsigned long long id = 0; hipGraph_t gr = nullptr;
+        const hipGraphNode_t* deps = nullptr; size_t n = 0;
+        TE_HIP_CHECK(hipStreamGetCaptureInfo_v2(cap, &status, &id, &gr, &deps, &n));
+        return Nodes(deps, deps + n);
+      };
+      TE_HIP_CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
       try {
-        TE_HIP_CHECK(hipEventRecord(branch_events_[0], root));
-        for (size_t b = 1; b < nb; ++b) TE_HIP_CHECK(hipStreamWaitEvent(branch_streams_[b], branch_events_[0], 0));
-        for (size_t b = 0; b < nb; ++b) batches_[b]->enqueue_sequence(branch_streams_[b], n_ticks, dt, specs[b], query, org, radius);
-        for (size_t b = 1; b < nb; ++b) {
-          TE_HIP_CHECK(hipEventRecord(branch_events_[b], branch_streams_[b]));
-          TE_HIP_CHECK(hipStreamWaitEvent(root, branch_events_[b], 0));
+        Nodes leaves, none;
+        for (size_t b = 0; b < nb; ++b) {
+          if (batches_[b]->size() == 0) continue;
+          set_deps(none);                                  // a new chain: no predecessor
+          for (long s = 0; s < n_ticks; ++s) batches_[b]->enqueue_tick(cap, s, dt, specs[b], query, org, radius);
+          const Nodes tail = captured();
+          leaves.insert(leaves.end(), tail.begin(), tail.end());
         }
+        TE_HIP_CHECK(hipGetLastError());
+        set_deps(leaves);
       } catch (...) {
         hipGraph_t broken = nullptr;
-        (void)hipStreamEndCapture(root, &broken);   // leave capture mode before reporting
+        (void)hipStreamEndCapture(cap, &broken);   // leave capture mode before reporting
         if (broken) (void)hipGraphDestroy(broken);
         throw;
       }
-      TE_HIP_CHECK(hipStreamEndCapture(root, &g.graph));
+      TE_HIP_CHECK(hipStreamEndCapture(cap, &g.graph));
       TE_HIP_CHECK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
       seq_graphs_.push_back(std::move(g));
       hit = &seq_graphs_.back();

@@ -106,9 +106,9 @@ class TargetManager {
 
   // n_ticks ticks of EVERY batch (specs in batch order), device-resident inputs: one step launch per
   // batch per tick, optionally followed by the own-time sphere query of every target.  The batches are
-  // independent, so with use_graph != 0 each batch's chain of launches is recorded on its own branch
-  // of one hipGraph (fork/join by events) and the branches run concurrently; use_graph == 2 records
-  // without launching.  use_graph == 0 issues the same launches eagerly, batch after batch per tick.
+  // independent, so with use_graph != 0 each batch's chain of launches is its own branch of one hipGraph
+  // and the branches run concurrently; the query runs inside the step kernel for the separable layouts
+  // and as a second launch of the chain for the dense ones.  use_graph == 2 records without launching.  use_graph == 0 issues the same launches eagerly, batch after batch per tick.
   void stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpec* specs, long n_specs, bool query,
                        const double* origin, double radius, int use_graph);
 
@@ -150,8 +150,8 @@ class TargetManager {
     hipGraph_t graph; hipGraphExec_t exec;
   };
   std::vector<SeqGraph> seq_graphs_;
-  std::vector<hipStream_t> branch_streams_;
-  std::vector<hipEvent_t> branch_events_;   // [0] = fork, [b] = join of branch b
+  std::vector<hipStream_t> branch_streams_;   // [0]: the capture stream
+  std::vector<hipEvent_t> branch_events_;
   void dropSeqGraphs();
 };
 

@@ -125,19 +125,19 @@ def test_convergence_gate_matches_oracle(models, name):
     mgr.close()
 
 
-@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("dtype,lanes", [("f64", 0), ("f32", 0), ("f64", 3), ("f32", 201)])
 @pytest.mark.parametrize("use_graph", [0, 1])
-def test_all_batches_sequence_equals_per_batch_calls(models, dtype, use_graph):
+def test_all_batches_sequence_equals_per_batch_calls(models, dtype, lanes, use_graph):
     """target_manager_step_sequence_all (the batches as concurrent branches of one hipGraph, with the per-tick
     own-time sphere query) == one target_batch_step + one intersect call per batch per tick, bit for bit."""
     from target_estimation_amd.streams import make_stream
     names = ["angular_rates", "uniform_acceleration", "angular_velocities"]
     sizes = [333, 1000, 77]
-    ticks, dt = 6, 0.004
+    ticks, dt = 7, 0.004            # odd: both state mirrors are in use when the sequence ends
     origin, radius = np.array([0.1, -0.2, 0.3]), 5.0
 
     def build():
-        mgr = te.TargetManager(dtype=dtype)
+        mgr = te.TargetManager(dtype=dtype, lanes_per_target=lanes)   # 3: dense kernel, 3 lanes per target
         mgr.set_stream(torch.cuda.current_stream().cuda_stream)
         base, meas = 0, []
         for k, (name, n) in enumerate(zip(names, sizes)):
