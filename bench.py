@@ -357,6 +357,74 @@ def cpu_baseline(name, targets=None, budget_s=6.0):
                 value_1thread=n_cpu * ticks1 / el1)
 
 
+def parity_report(te, torch, name, n_sample=256, checkpoints=(1, 100, 1000)):
+    """parity next to the perf number.  A sample of the same workload (same model, precision, layout
+    choice and stream generator) stepped on the GPU and by the CPU oracle; errors after 1 / 100 / 1000 ticks.
+    The oracle is the checker here, nothing of it is timed."""
+    import numpy as np
+    import oracle
+    from target_estimation_amd.streams import make_stream
+    desc, model, dtype, _, seed = WORKLOADS[name]
+    m = oracle.load_model_yaml(os.path.join(ROOT, "models", "model_%s_params.yaml" % model))
+    dt, ticks = 1.0 / 250.0, max(checkpoints)
+    st = make_stream(te.MODEL_TYPES[model], n_sample, ticks, dt, seed)
+    p0 = st["p0"].cpu().numpy()
+    ids = np.arange(n_sample, dtype=np.uint32)
+    mgr = te.TargetManager(os.path.join(ROOT, "models", "model_%s_params.yaml" % model), dtype=dtype, lanes_per_target=TUNED_LANES.get(name, 0))
+    mgr.set_stream(torch.cuda.current_stream().cuda_stream)
+    mgr.init_batch(ids, dt, 0.0, p0)
+    b = mgr.batches()[0]
+    meas = st["meas"].to(b.torch_dtype()).contiguous()
+    meas_host = meas.to(torch.float64).cpu().numpy()           # the oracle sees what the kernel saw
+    orc = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], p0, dt, dtype=dtype)
+    rep = dict(targets=n_sample, layout=b.layout, ticks=list(checkpoints), max_abs_x=[], max_rel_x=[], max_rel_P=[],
+               ids_exact=bool((b.slot_ids() == ids).all()), oracle="oracle/te_oracle.c, same precision (%s)" % dtype,
+               tolerance=("x: 1e-10 + 1e-10|x|, P: 1e-9 max|P|" if dtype == "f64" else "x: 2e-3 + 1e-4|x|, P: 2e-3 max|P|"))
+    for s in range(ticks):
+        b.step(dt, meas[s])
+        orc.step(dt, np.ascontiguousarray(meas_host[s].T))
+        if s + 1 in checkpoints:
+            x, P = mgr.get_state_batch(ids)
+            xo, Po = orc.state()
+            rep["max_abs_x"].append(float(np.abs(x - xo).max()))
+            rep["max_rel_x"].append(float((np.abs(x - xo) / np.maximum(np.abs(xo), 1e-3)).max()))
+            rep["max_rel_P"].append(float((np.abs(P - Po) / np.abs(Po).max(axis=(1, 2), keepdims=True)).max()))
+    mgr.close()
+    return rep
+
+
+def copy_bandwidth(torch, nbytes=1 << 30, reps=10):
+    """Streaming rates of this box in GB/s (bytes read + bytes written per second), the practical HBM ceilings SURVEY 8d
+    asks to record next to the 8 TB/s spec peak: a device-to-device copy (dst.copy_(src): 1 read + 1 write) and a triad
+    (c = a + b on fp32: 2 reads + 1 write), both over 1 GiB arrays (larger than the 256 MB Infinity Cache)."""
+    n = nbytes // 4
+    a = torch.zeros(n, dtype=torch.float32, device="cuda")
+    b = torch.ones(n, dtype=torch.float32, device="cuda")
+    c = torch.empty_like(a)
+
+    def rate(fn, bytes_per_call):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return bytes_per_call * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    return dict(copy=rate(lambda: c.copy_(a), 2.0 * nbytes), triad=rate(lambda: torch.add(a, b, out=c), 3.0 * nbytes))
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -440,6 +508,21 @@ def main():
             out["roofline"]["launch_floor_error"] = str(exc)[:200]
     if world == 1 and rank == 0 and not args.no_cpu and args.workload in WORKLOADS:
         out["cpu_baseline"] = cpu_baseline(args.workload, args.targets or None)
+        out["cpu_baseline"]["cpu_model"] = cpu_model()
+        try:
+            out["parity"] = parity_report(te, torch, args.workload)
+        except Exception as exc:   # a diagnostic: never let it break the bench line
+            out["parity"] = {"error": str(exc)[:300]}
+    if world == 1 and rank == 0:
+        try:
+            bw = copy_bandwidth(torch)
+            out["roofline"]["measured_copy_gbs"] = bw["copy"]
+            out["roofline"]["measured_triad_gbs"] = bw["triad"]
+            out["roofline"]["frac_of_measured_stream"] = res["achieved_gbs"] / max(bw.values())
+            out["roofline"]["measured_stream_note"] = ("torch dst.copy_(src) and torch.add(a, b, out=c) over 1 GiB fp32 arrays on this box; "
+                                                       "frac_of_measured_stream uses the larger of the two")
+        except Exception as exc:
+            out["roofline"]["copy_bandwidth_error"] = str(exc)[:200]
     # Extra workloads in the same line.  One GPU: the full list.  Several GPUs: one 10^6-targets-per-GPU
     # workload per YAML motion model plus configs[3], every rank in lockstep (same barriers, max over
     # ranks), so that the scaling curve exists for each model and not only for the headline workload.
