@@ -433,10 +433,11 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + sorted(MIXED))
     ap.add_argument("--lanes", type=int, default=0, help="lanes per target (0 = tuned default)")
     ap.add_argument("--targets", type=int, default=0, help="override targets per GPU")
-    ap.add_argument("--extra", default="cfg3,cfg4,cfg5,uv1m,ua1m,av1m,ar1m,ar1m_s201,av1m_s201,cfg2_full,uv1m_full,uv1m_packed,ar1m_full", help="comma list of extra workloads reported under 'extra' (N=1 only; '' = none)")
+    ap.add_argument("--extra", default="cfg3,cfg4,cfg5,cfg4x8,cfg5x8,uv1m,ua1m,av1m,ar1m,ar1m_s201,av1m_s201,cfg2_full,uv1m_full,uv1m_packed,ar1m_full", help="comma list of extra workloads reported under 'extra' (N=1 only; '' = none)")
     ap.add_argument("--extra-multi", default="uv1m,ua1m,av1m,ar1m,cfg4,cfg5",
                     help="extra workloads when --gpus > 1 (per-GPU sizes; every rank runs them in lockstep)")
     ap.add_argument("--extra-steps", type=int, default=50)
+    ap.add_argument("--scale", type=int, default=1, help="mixed workloads (cfg4/cfg5): multiply the per-GPU populations (8 = all 10^6 targets on one GPU)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--gather", action="store_true",
                     help="after the timed region, gather every rank's pose7 rows to rank 0 (RCCL gather over xGMI) and report its time; "
@@ -459,7 +460,7 @@ def main():
     import target_estimation_amd as te
 
     if args.workload in MIXED:
-        res = run_mixed(te, torch, args.workload, args.steps, args.warmup, dist, rank, world,
+        res = run_mixed(te, torch, args.workload, args.steps, args.warmup, dist, rank, world, scale=args.scale,
                         launch_mode="graph" if args.launch_mode == "fused" else args.launch_mode)
         mgr = None
     else:
@@ -533,9 +534,14 @@ def main():
     for name in extra_names:
         if name == args.workload:
             continue
-        if name in MIXED:
-            r = run_mixed(te, torch, name, max(args.extra_steps, 200), 20, dist, rank, world,
-                              launch_mode="graph" if args.launch_mode == "fused" else args.launch_mode)
+        base, _, mult = name.partition("x")            # "cfg5x8": 8 x the per-GPU share = all 10^6 targets on this GPU
+        if base in MIXED:
+            sc = int(mult) if mult else 1
+            r = run_mixed(te, torch, base, max(args.extra_steps, 200) if sc == 1 else args.extra_steps, 20, dist, rank, world, scale=sc,
+                          launch_mode="graph" if args.launch_mode == "fused" else args.launch_mode)
+            r["name"] = name
+            if sc > 1:
+                r["desc"] += " -- x%d: the whole population on this GPU" % sc
         else:
             small = WORKLOADS[name][3] <= 20000
             r = run_workload(te, torch, name, 1920 if small else args.extra_steps, 64 if small else 10, 0,
