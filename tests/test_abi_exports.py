@@ -57,3 +57,30 @@ def test_yaml_models_match_generator(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_models.py"), str(tmp_path)])
     for f in os.listdir(os.path.join(ROOT, "models")):
         assert open(os.path.join(ROOT, "models", f)).read() == open(os.path.join(str(tmp_path), f)).read()
+
+
+def test_null_handles_are_errors_not_crashes(capfd):
+    """Every entry point reports a NULL handle (message, error value) instead of dereferencing it; no GPU needed."""
+    import ctypes as C
+    import numpy as np
+    from target_estimation_amd import capi
+    lib = capi.lib()
+    p7 = np.zeros(7)
+    dp = p7.ctypes.data_as(capi.c_double_p)
+    lib.target_manager_init(None, 1, 0.004, dp, 0.0)
+    lib.target_manager_update_meas(None, 1, 0.004, dp)
+    lib.target_manager_update(None, 1, 0.004)
+    assert not lib.target_manager_get_est_pose(None, 1, dp)
+    assert not lib.target_manager_get_est_twist(None, 1, dp)
+    assert not lib.target_manager_get_est_acceleration(None, 1, dp)
+    assert lib.target_manager_get_n_measurements(None, 1) == 0
+    lib.target_manager_log(None)
+    lib.target_manager_delete(None)
+    assert lib.target_manager_num_batches(None) == -1
+    assert not lib.target_manager_get_batch(None, 0)
+    assert lib.target_batch_size(None) == -1
+    assert lib.target_batch_step(None, 0.004, None, 0, None) != 0
+    assert lib.target_manager_step_sequence_all(None, 1, 0.004, None, 0, 0, None, 0.0, 0) != 0
+    assert lib.target_manager_size(None) < 0
+    assert b"NULL" in lib.target_manager_last_error()
+    assert "NULL manager handle" in capfd.readouterr().err
