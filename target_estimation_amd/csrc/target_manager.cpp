@@ -136,10 +136,7 @@ int TargetManager::findOrCreateBatch(int type, const double* Q, const double* R,
 }
 
 bool TargetManager::find(unsigned id, Loc& loc) {
-  auto it = targets_.find(id);
-  if (it == targets_.end()) return false;
-  loc = it->second;
-  return true;
+  return targets_.find(id, loc);
 }
 
 void TargetManager::log() {
@@ -175,8 +172,7 @@ void TargetManager::log() {
 std::vector<unsigned> TargetManager::getAvailableTargets() {
   std::vector<unsigned> ids;
   lock_guard<mutex> lg(target_lock_);
-  ids.reserve(targets_.size());
-  for (auto const& kv : targets_) ids.push_back(kv.first);
+  ids = targets_.sorted_ids();   // ascending, as the reference's std::map iteration
   return ids;
 }
 
@@ -187,7 +183,7 @@ size_t TargetManager::size() {
 
 bool TargetManager::hasTarget(unsigned id) {
   lock_guard<mutex> lg(target_lock_);
-  return targets_.count(id) != 0;
+  return targets_.contains(id);
 }
 
 void TargetManager::init(unsigned id, double dt0, double t0, const double* p0, const double* v0, const double* a0) {
@@ -201,10 +197,10 @@ void TargetManager::init(target_t type, unsigned id, double dt0, double t0, cons
                          const double* P0, const double* p0, const double* v0, const double* a0) {
   (void)dt0;  // only shapes the constructor's A, which every step rebuilds (uniform_velocity.cpp:40,67)
   lock_guard<mutex> lg(target_lock_);
-  if (targets_.find(id) == targets_.end()) {
+  if (!targets_.contains(id)) {
     const int b = findOrCreateBatch((int)type, Q, R, chooseLayout((int)type, Q, R, P0, 1));
     const long slot = batches_[(size_t)b]->append(1, &id, t0, P0, false, p0, v0 ? v0 : kZero6, a0 ? a0 : kZero6);
-    targets_[id] = Loc{b, (int)slot};
+    targets_.set(id, Loc{b, (int)slot});
     if (verbose_) {
       switch (type) {
         case ANGULAR_RATES: std::cout << "Using angular rates for the orientation" << std::endl; break;
@@ -241,13 +237,14 @@ long TargetManager::initBatch(target_t type, const unsigned* ids, long n, double
   std::vector<long> keep;
   keep.reserve((size_t)n);
   {
-    std::map<unsigned, int> seen;
+    IdTable seen;
+    seen.reserve((size_t)n);
     for (long i = 0; i < n; ++i) {
-      if (targets_.count(ids[i]) || seen.count(ids[i])) {
+      if (targets_.contains(ids[i]) || seen.contains(ids[i])) {
         if (verbose_) std::cout << "Target(" << ids[i] << ") already exists!" << std::endl;
         continue;
       }
-      seen[ids[i]] = 1;
+      seen.set(ids[i], Loc{0, 0});
       keep.push_back(i);
     }
   }
@@ -274,7 +271,8 @@ long TargetManager::initBatch(target_t type, const unsigned* ids, long n, double
     first = batches_[(size_t)b]->append(k, ids2.data(), t0, per_target_P0 ? P2.data() : P0, per_target_P0, p2.data(),
                                         v0 ? v2.data() : nullptr, a0 ? a2.data() : nullptr);
   }
-  for (long j = 0; j < k; ++j) targets_[ids[keep[(size_t)j]]] = Loc{b, (int)(first + j)};
+  targets_.reserve(targets_.size() + (size_t)k);
+  for (long j = 0; j < k; ++j) targets_.set(ids[keep[(size_t)j]], Loc{b, (int)(first + j)});
   return k;
 }
 
@@ -316,7 +314,7 @@ bool TargetManager::erase(unsigned id) {
   const bool was_last = loc.slot == b->size() - 1;
   const unsigned moved = b->erase_slot(loc.slot);
   targets_.erase(id);
-  if (!was_last) targets_[moved].slot = loc.slot;
+  if (!was_last) targets_.set(moved, Loc{loc.batch, loc.slot});
   return true;
 }
 

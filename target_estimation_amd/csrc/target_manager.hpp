@@ -8,7 +8,8 @@
 //   MatrixXd Q, R, P0   -> row-major const double[n*n] / [m*m]
 // Differences, all deliberate:
 //   * targets live in HBM, grouped into one Batch per (model, Q, R); the id -> (batch, slot)
-//     map is a std::map as in the reference, so enumeration stays ascending by id;
+//     map is a hash table (id_table.hpp) and enumeration sorts, so it stays ascending by id as
+//     with the reference's std::map;
 //   * the per-target constructor dump (printInfo, target_interface.cpp:57-78) and the per-target
 //     type line (target_manager.cpp:161-173) are printed only when verbose (env
 //     TARGET_ESTIMATION_VERBOSE=1): a million-target init must not write a million dumps;
@@ -23,6 +24,7 @@
 #include <vector>
 
 #include "batch_store.hpp"
+#include "id_table.hpp"
 
 namespace te {
 
@@ -122,7 +124,7 @@ class TargetManager {
   int defaultType() const { return (int)default_type_; }
 
  protected:
-  struct Loc { int batch; int slot; };
+  using Loc = TargetLoc;
   bool loadYamlFile(const std::string& file, std::vector<double>& Q, std::vector<double>& R, std::vector<double>& P,
                     target_t& type);  // target_manager.cpp:67-104
   // lanes code of a new target's batch: the manager's explicit choice, or (auto) the axis-separable
@@ -131,7 +133,7 @@ class TargetManager {
   int findOrCreateBatch(int type, const double* Q, const double* R, int lanes_code);
   bool find(unsigned id, Loc& loc);
 
-  std::map<unsigned, Loc> targets_;
+  IdTable targets_;   // id -> (batch, slot); the reference's std::map<unsigned, TargetPtr> (target_manager.hpp:201)
   std::vector<std::unique_ptr<Batch>> batches_;
   std::mutex target_lock_;
   std::vector<double> default_Q_, default_P_, default_R_;

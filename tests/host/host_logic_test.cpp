@@ -7,6 +7,10 @@
 #include <set>
 #include <string>
 
+#include <map>
+#include <random>
+
+#include "../../target_estimation_amd/csrc/id_table.hpp"
 #include "../../target_estimation_amd/csrc/te_layout.hpp"
 #include "../../target_estimation_amd/csrc/yaml_mini.hpp"
 
@@ -53,7 +57,55 @@ void check_layout(const char* name) {
   std::printf("layout %-28s RW %3d tile %6ld B (%5.1f B/target)\n", name, C::RW, C::TILE_BYTES, (double)C::TILE_BYTES / C::TPW);
 }
 
+// the manager's id table against std::map under a random mix of insert / overwrite / erase / lookup,
+// with ids that collide in the table (multiples of large powers of two) and dense ranges
+static void check_id_table() {
+  std::mt19937 g(5);
+  te::IdTable t;
+  std::map<unsigned, te::TargetLoc> ref;
+  auto pick = [&]() -> unsigned {
+    switch (g() % 4) {
+      case 0: return g() % 512;                         // dense, many repeats
+      case 1: return (g() % 256) << 20;                 // same low bits
+      case 2: return 0xFFFFFFFFu - (g() % 64);          // top of the range
+      default: return g();
+    }
+  };
+  for (int it = 0; it < 400000; ++it) {
+    const unsigned id = pick();
+    const int op = g() % 8;
+    if (op < 4) {
+      const te::TargetLoc loc{(int)(g() % 3), (int)(g() % 100000)};
+      t.set(id, loc); ref[id] = loc;
+    } else if (op < 6) {
+      const bool a = t.erase(id), b = ref.erase(id) != 0;
+      CHECK(a == b);
+    } else {
+      te::TargetLoc loc{-7, -7};
+      const bool a = t.find(id, loc);
+      auto f = ref.find(id);
+      CHECK(a == (f != ref.end()));
+      CHECK(t.contains(id) == a);
+      if (a && f != ref.end()) { CHECK(loc.batch == f->second.batch && loc.slot == f->second.slot); }
+    }
+    if (it % 50000 == 0) {
+      CHECK(t.size() == ref.size());
+      const std::vector<unsigned> ids = t.sorted_ids();
+      CHECK(ids.size() == ref.size());
+      size_t k = 0;
+      for (auto const& kv : ref) { CHECK(k < ids.size() && ids[k] == kv.first); ++k; }   // ascending, as std::map
+    }
+  }
+  te::IdTable big;
+  big.reserve(1000000);
+  for (unsigned i = 0; i < 1000000; ++i) big.set(i * 7u + 3u, te::TargetLoc{0, (int)i});
+  te::TargetLoc loc;
+  CHECK(big.size() == 1000000 && big.find(7u * 999999u + 3u, loc) && loc.slot == 999999 && !big.contains(4u));
+  std::printf("id table ok (%zu live ids after the random schedule)\n", t.size());
+}
+
 int main(int argc, char** argv) {
+  check_id_table();
   check_layout<ModelUV, double, 1, LAYOUT_FULL>("UV f64 G1 full");
   check_layout<ModelUV, double, 3, LAYOUT_FULL>("UV f64 G3 full");
   check_layout<ModelUV, float, 3, LAYOUT_FULL>("UV f32 G3 full");

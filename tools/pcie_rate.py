@@ -37,6 +37,19 @@ def main():
         for _ in range(args.ticks):
             mgr.update_batch(ids, 0.004, meas)
         ta = (time.perf_counter() - t0) / args.ticks
+        # the same call with the ids in random order (no slot-order fast path: one id lookup per row) and the getters
+        perm = rng.permutation(n)
+        ids_r, meas_r = ids[perm], np.ascontiguousarray(meas[perm])
+        mgr.update_batch(ids_r, 0.004, meas_r)
+        t0 = time.perf_counter()
+        for _ in range(max(3, args.ticks // 5)):
+            mgr.update_batch(ids_r, 0.004, meas_r)
+        tr = (time.perf_counter() - t0) / max(3, args.ticks // 5)
+        t0 = time.perf_counter()
+        for _ in range(max(3, args.ticks // 5)):
+            mgr.get_est_batch(ids_r)
+        tg = (time.perf_counter() - t0) / max(3, args.ticks // 5)
+        print("%s %s N=%d: by-ids in random order %.1f us/tick | get_est_batch (pose+twist+acc to host, random order) %.1f us" % (args.model, args.dtype, n, tr * 1e6, tg * 1e6), flush=True)
         pinned = torch.from_numpy(np.ascontiguousarray(meas.T)).to(b.torch_dtype()).contiguous().pin_memory()
         dev = torch.empty_like(pinned, device="cuda")
         dev.copy_(pinned, non_blocking=True); b.step(0.004, dev); torch.cuda.synchronize()
