@@ -33,6 +33,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 TUNED_LANES = {"cfg2_full": 3, "uv1m_full": 1, "ua1m_full": 1, "ar1m_full": 6, "av1m_full": 3, "uv1m_packed": 101,
                "uv1m_s201": 201, "ua1m_s201": 201, "av1m_s201": 201, "ar1m_s201": 201}
 
+# stream variants: availability < 1 = per-(target, tick) measurement mask (predict-only otherwise); rpy_noise = orientation noise
+VARIANTS = {"ar1m_a90": dict(availability=0.9, rpy_noise=0.1), "av1m_a90": dict(availability=0.9, rpy_noise=0.1)}
+
 WORKLOADS = {
     # name: (description, model, dtype, targets per GPU, seed)
     "cfg2": ("10000 targets, uniform-velocity model, fp64 (BASELINE.json configs[1])", "uniform_velocity", "f64", 10_000, 20240002),
@@ -53,6 +56,8 @@ WORKLOADS = {
     "ua1m_s201": ("1000000 targets, uniform-acceleration model, fp32, axis-separable layout with full group blocks", "uniform_acceleration", "f32", 1_000_000, 20240013),
     "av1m_s201": ("1000000 targets, angular-velocities model, fp32, axis-separable layout with full group blocks", "angular_velocities", "f32", 1_000_000, 20240015),
     "ar1m_s201": ("1000000 targets, angular-rates model, fp32, axis-separable layout with full group blocks", "angular_rates", "f32", 1_000_000, 20240014),
+    "ar1m_a90": ("1000000 targets, angular-rates model, fp32, measurements on 90 % of the (target, tick) pairs, orientation noise 0.1 rad (SURVEY 8d variant)", "angular_rates", "f32", 1_000_000, 20240018),
+    "av1m_a90": ("1000000 targets, angular-velocities model, fp32, measurements on 90 % of the (target, tick) pairs, orientation noise 0.1 rad (SURVEY 8d variant)", "angular_velocities", "f32", 1_000_000, 20240019),
     "ar1m64": ("1000000 targets, angular-rates model, fp64", "angular_rates", "f64", 1_000_000, 20240016),
     "av1m64": ("1000000 targets, angular-velocities model, fp64", "angular_velocities", "f64", 1_000_000, 20240017),
 }
@@ -188,7 +193,8 @@ def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None,
     mtype = te.MODEL_TYPES[model]
     dt = 1.0 / 250.0
     ticks = min(stream_ticks, steps + warmup)
-    st = make_stream(mtype, n_targets, ticks, dt, seed + 1000 * rank)
+    st = make_stream(mtype, n_targets, ticks, dt, seed + 1000 * rank, **VARIANTS.get(name, {}))
+    has = st["has_meas"]    # [ticks, N] uint8 or None
     import numpy as np
     ids = np.arange(n_targets, dtype=np.uint32) + rank * n_targets  # global ids: rank-contiguous shards
     mgr.init_batch(ids, dt, 0.0, st["p0"].cpu().numpy())
@@ -204,7 +210,7 @@ def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None,
     def run_ticks(count):
         if launch_mode == "python":
             for _ in range(count):
-                b.step(dt, meas[done[0] % ticks])
+                b.step(dt, meas[done[0] % ticks], None if has is None else has[done[0] % ticks])
                 done[0] += 1
             return
         while count > 0:
@@ -213,14 +219,15 @@ def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None,
             # only whole blocks are replayed from the recorded graph (one graph, recorded during
             # warm-up); partial blocks are enqueued launch by launch
             if launch_mode == "fused":   # temporally fused: the whole block in ONE launch ("effective" metric)
-                b.step_fused(dt, meas[off:off + blk])
+                b.step_fused(dt, meas[off:off + blk], None if has is None else has[off:off + blk])
             else:
-                b.step_sequence(dt, meas[off:off + blk], use_graph=(launch_mode == "graph" and off == 0 and blk == ticks))
+                b.step_sequence(dt, meas[off:off + blk], None if has is None else has[off:off + blk],
+                                use_graph=(launch_mode == "graph" and off == 0 and blk == ticks))
             done[0] += blk
             count -= blk
 
     if launch_mode == "graph":
-        b.step_sequence(dt, meas, use_graph=2)   # record the block's graph now (set-up; launches nothing)
+        b.step_sequence(dt, meas, has, use_graph=2)   # record the block's graph now (set-up; launches nothing)
     run_ticks(warmup)
     torch.cuda.synchronize()
     if dist is not None:
@@ -433,7 +440,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + sorted(MIXED))
     ap.add_argument("--lanes", type=int, default=0, help="lanes per target (0 = tuned default)")
     ap.add_argument("--targets", type=int, default=0, help="override targets per GPU")
-    ap.add_argument("--extra", default="cfg3,cfg4,cfg5,cfg4x8,cfg5x8,uv1m,ua1m,av1m,ar1m,ar1m_s201,av1m_s201,cfg2_full,uv1m_full,uv1m_packed,ar1m_full", help="comma list of extra workloads reported under 'extra' (N=1 only; '' = none)")
+    ap.add_argument("--extra", default="cfg3,cfg4,cfg5,cfg4x8,cfg5x8,uv1m,ua1m,av1m,ar1m,ar1m_a90,av1m_a90,ar1m_s201,av1m_s201,cfg2_full,uv1m_full,uv1m_packed,ar1m_full", help="comma list of extra workloads reported under 'extra' (N=1 only; '' = none)")
     ap.add_argument("--extra-multi", default="uv1m,ua1m,av1m,ar1m,cfg4,cfg5",
                     help="extra workloads when --gpus > 1 (per-GPU sizes; every rank runs them in lockstep)")
     ap.add_argument("--extra-steps", type=int, default=50)

@@ -28,9 +28,11 @@ def qtran_matrix(dt, omega):
     return torch.where((n > 0)[:, None, None], M, eye)
 
 
-def make_stream(model, n_targets, ticks, dt, seed, device="cuda", availability=1.0):
+def make_stream(model, n_targets, ticks, dt, seed, device="cuda", availability=1.0, rpy_noise=0.0):
     """Returns dict(p0 [N,7] f64 (pose at t=0), meas [ticks,7,N] f64 SoA (pose at t=(s+1)dt),
-    has_meas [ticks,N] uint8 or None, v, a, omega truth)."""
+    has_meas [ticks,N] uint8 or None, v, a, omega truth).  availability < 1: each target has a measurement on a tick
+    with that probability (predict-only otherwise); rpy_noise > 0: the measured orientation is the true one
+    rotated by a small random rotation vector of that standard deviation per axis (rad)."""
     g = torch.Generator(device=device)
     g.manual_seed(int(seed))
     f64 = dict(dtype=torch.float64, device=device)
@@ -53,7 +55,16 @@ def make_stream(model, n_targets, ticks, dt, seed, device="cuda", availability=1
         q = q / q.norm(dim=1, keepdim=True)
         pos = p + v * t + 0.5 * a * (t * t)
         meas[s, 0:3] = (pos + 0.01 * torch.randn(N, 3, generator=g, **f64)).T
-        meas[s, 3:7] = q.T
+        qm = q
+        if rpy_noise > 0.0:
+            h = 0.5 * rpy_noise * torch.randn(N, 3, generator=g, **f64)          # half rotation vector
+            dq = torch.cat([h, torch.ones(N, 1, **f64)], 1)
+            dq = dq / dq.norm(dim=1, keepdim=True)
+            x1, y1, z1, w1 = q.unbind(1)
+            x2, y2, z2, w2 = dq.unbind(1)
+            qm = torch.stack([w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+                              w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2, w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2], 1)
+        meas[s, 3:7] = qm.T
     has = None
     if availability < 1.0:
         has = (torch.rand(ticks, N, generator=g, device=device) < availability).to(torch.uint8)
