@@ -550,7 +550,7 @@ def main():
             if sc > 1:
                 r["desc"] += " -- x%d: the whole population on this GPU" % sc
         else:
-            small = WORKLOADS[name][3] <= 20000
+            small = WORKLOADS[name][3] <= 200000
             r = run_workload(te, torch, name, 1920 if small else args.extra_steps, 64 if small else 10, 0,
                              dist=dist, rank=rank, world=world, launch_mode=args.launch_mode)
             r.pop("_mgr")
