@@ -74,6 +74,10 @@ long target_manager_init_batch_typed(target_manager_c* self, int type, const uns
                                      int per_target_P0, const double* p0, const double* v0, const double* a0);
 /* TargetManager::erase, target_manager.cpp:227-241.  1 = erased, 0 = unknown id. */
 int target_manager_erase(target_manager_c* self, unsigned int id);
+/* the same for n ids in one call: one compaction launch per batch instead of one launch per target
+ * (a timeout storm in the ingest stage).  Unknown or repeated ids print the reference's message and are
+ * skipped.  Returns the number erased (or < 0). */
+long target_manager_erase_batch(target_manager_c* self, const unsigned int* ids, long n);
 long target_manager_size(target_manager_c* self);
 /* TargetManager::getAvailableTargets (ascending ids), target_manager.cpp:126-133 */
 long target_manager_get_available_targets(target_manager_c* self, unsigned int* ids_out, long capacity);

@@ -47,6 +47,7 @@ SIGNATURES = {
                                                    c_double_p, c_double_p, c_double_p, C.c_int, c_double_p,
                                                    c_double_p, c_double_p]),
     "target_manager_erase": (C.c_int, [C.c_void_p, C.c_uint]),
+    "target_manager_erase_batch": (C.c_long, [C.c_void_p, C.POINTER(C.c_uint), C.c_long]),
     "target_manager_size": (C.c_long, [C.c_void_p]),
     "target_manager_get_available_targets": (C.c_long, [C.c_void_p, c_uint_p, C.c_long]),
     "target_manager_update_meas_batch": (C.c_long, [C.c_void_p, c_uint_p, C.c_long, C.c_double, c_double_p, c_ubyte_p]),

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstring>
 #include <limits>
+#include <stdexcept>
 
 #include "hip_check.hpp"
 #include "intersect_gate.hpp"
@@ -172,6 +173,44 @@ unsigned Batch::erase_slot(long slot) {
   slot_ids_.pop_back();
   n_ = last;
   return moved;
+}
+
+void Batch::erase_slots(const int* slots, long k, std::vector<std::pair<unsigned, int>>& moves_out) {
+  touch();
+  moves_out.clear();
+  if (k <= 0) return;
+  const long new_n = n_ - k;
+  std::vector<unsigned char> gone((size_t)n_, 0);
+  for (long j = 0; j < k; ++j) {
+    if (slots[j] < 0 || slots[j] >= n_ || gone[(size_t)slots[j]]) throw std::runtime_error("target_estimation_amd: erase_slots: bad or repeated slot");
+    gone[(size_t)slots[j]] = 1;
+  }
+  // holes below the new size are filled, in order, by the survivors at or above it
+  std::vector<int> src, dst;
+  long tail = new_n;
+  for (long hole = 0; hole < new_n; ++hole) {
+    if (!gone[(size_t)hole]) continue;
+    while (gone[(size_t)tail]) ++tail;
+    src.push_back((int)tail); dst.push_back((int)hole);
+    ++tail;
+  }
+  const long m = (long)src.size();
+  if (m > 0) {
+    stage_reserve(2 * m);
+    TE_HIP_CHECK(hipMemcpyAsync(d_idx_, src.data(), sizeof(int) * (size_t)m, hipMemcpyHostToDevice, stream_));
+    TE_HIP_CHECK(hipMemcpyAsync(d_idx_ + m, dst.data(), sizeof(int) * (size_t)m, hipMemcpyHostToDevice, stream_));
+    ops_->move_records(d_rec_, d_idx_, d_idx_ + m, m, d_tbase_, d_nmbase_, stream_);
+    TE_HIP_CHECK(hipGetLastError());
+    for (long j = 0; j < m; ++j) {
+      gate_move(src[(size_t)j], dst[(size_t)j]);
+      const unsigned id = slot_ids_[(size_t)src[(size_t)j]];
+      slot_ids_[(size_t)dst[(size_t)j]] = id;
+      moves_out.emplace_back(id, dst[(size_t)j]);
+    }
+    TE_HIP_CHECK(hipStreamSynchronize(stream_));   // src / dst go out of scope
+  }
+  slot_ids_.resize((size_t)new_n);
+  n_ = new_n;
 }
 
 void Batch::step_dense(double dt, const void* meas_dev, long ld, const unsigned char* has_dev) {

@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <utility>
 #include <vector>
 
 #include "kf_ops.hpp"
@@ -41,6 +42,9 @@ class Batch {
   // Remove a slot by moving the last slot into it; returns the id that now lives in `slot`
   // (or the erased id if it was the last one).
   unsigned erase_slot(long slot);
+  // Erase many slots at once (distinct slots, any order): survivors from the tail fill the holes below
+  // the new size in ONE launch.  moves_out lists (id, new slot) of every target that changed slot.
+  void erase_slots(const int* slots, long k, std::vector<std::pair<unsigned, int>>& moves_out);
 
   // One tick over every target, device-resident inputs (the fast path).
   //   meas_dev: SoA [7][ld] in the batch precision, or null (predict only = TargetInterface::update)

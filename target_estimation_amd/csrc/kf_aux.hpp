@@ -157,6 +157,20 @@ __global__ void move_record_kernel(char* rec, long src, long dst, double* t_base
   if (tid == 0) { t_base[dst] = t_base[src]; nm_base[dst] = nm_base[src]; }
 }
 
+// m independent moves at once (batched erase: survivors from the tail fill the holes); blockIdx.y = move
+template <class M, typename T, int G, int LAYOUT>
+__global__ void move_records_kernel(char* rec, const int* src, const int* dst, long m, double* t_base, int* nm_base) {
+  using C = Cfg<M, T, G, LAYOUT>;
+  const long mv = blockIdx.y;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mv >= m || tid >= C::G * C::RW) return;
+  const long s = src[mv], d = dst[mv];
+  const int i = tid / C::RW, w = tid % C::RW;
+  const T v = *reinterpret_cast<T*>(rec + (s / C::TPW) * C::TILE_BYTES + record_word_offset<C, T>((int)(s % C::TPW) * C::G + i, w));
+  *reinterpret_cast<T*>(rec + (d / C::TPW) * C::TILE_BYTES + record_word_offset<C, T>((int)(d % C::TPW) * C::G + i, w)) = v;
+  if (tid == 0) { t_base[d] = t_base[s]; nm_base[d] = nm_base[s]; }
+}
+
 // measurements: AoS doubles [n][7] (the reference's Vector7d rows) -> SoA T [7][ld]
 template <typename T>
 __global__ void pack_meas_kernel(const double* aos, long n, T* soa, long ld) {

@@ -40,6 +40,7 @@ struct Ops {
   void (*get_state)(char* rec, const int* idx, long n, double* x, double* P, hipStream_t);
   void (*set_state)(char* rec, const int* idx, long n, const double* x, const double* P, const double* uw, hipStream_t);
   void (*move_record)(char* rec, long src, long dst, double* t_base, int* nm_base, hipStream_t);
+  void (*move_records)(char* rec, const int* src_dev, const int* dst_dev, long m, double* t_base, int* nm_base, hipStream_t);
   void (*outputs)(const OutArgs&, hipStream_t);
   void (*pack_meas)(const double* aos, long n, void* soa, long ld, hipStream_t);
   void (*intersect)(const IntersectArgs&, hipStream_t);

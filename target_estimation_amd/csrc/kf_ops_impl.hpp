@@ -5,6 +5,7 @@
 #include "kf_step.hpp"
 #include "kf_step_sep.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <stdexcept>
 
@@ -67,6 +68,14 @@ struct OpsImpl {
     const long th = n * C::N;
     hipLaunchKernelGGL((set_state_kernel<M, T, G, LAYOUT>), dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, rec, idx, n, x, P, uw);
   }
+  static void move_records(char* rec, const int* src, const int* dst, long m, double* t_base, int* nm_base, hipStream_t s) {
+    const int th = C::G * C::RW;
+    for (long done = 0; done < m; done += 65535) {   // grid.y limit
+      const long part = std::min<long>(65535, m - done);
+      hipLaunchKernelGGL((move_records_kernel<M, T, G, LAYOUT>), dim3((th + 255) / 256, (unsigned)part), dim3(256), 0, s, rec, src + done,
+                         dst + done, part, t_base, nm_base);
+    }
+  }
   static void move_record(char* rec, long src, long dst, double* t_base, int* nm_base, hipStream_t s) {
     const int th = C::G * C::RW;
     hipLaunchKernelGGL((move_record_kernel<M, T, G, LAYOUT>), dim3((th + 255) / 256), dim3(256), 0, s, rec, src, dst, t_base, nm_base);
@@ -86,7 +95,7 @@ struct OpsImpl {
   static const Ops* get() {
     static const Ops ops = {
         LayoutInfo{C::N, C::K, G, LAYOUT, C::TPW, C::LPT, C::RW, C::TILE_BYTES, C::TILE_PAYLOAD},
-        C::WPB, C::SEP, &step, &init, &get_state, &set_state, &move_record, &outputs, &pack_meas, &intersect};
+        C::WPB, C::SEP, &step, &init, &get_state, &set_state, &move_record, &move_records, &outputs, &pack_meas, &intersect};
     return &ops;
   }
 };

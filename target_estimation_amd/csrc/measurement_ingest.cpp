@@ -80,11 +80,13 @@ long MeasurementIngest::tick(double dt, double now, std::vector<unsigned>& ids_o
                           nullptr, nullptr);
   }
   if (!ids.empty()) manager_->updateBatch(ids.data(), (long)ids.size(), dt, meas.data(), has.data());  // :60,:64
+  std::vector<unsigned> to_erase;
   for (unsigned id : expired) {             // :67-72
     std::cerr << "Timeout for target " << id << std::endl;
     measurements_.erase(id);
-    if (manager_->hasTarget(id)) manager_->erase(id);
+    if (manager_->hasTarget(id)) to_erase.push_back(id);
   }
+  if (!to_erase.empty()) manager_->eraseBatch(to_erase.data(), (long)to_erase.size());   // one compaction launch per batch
   ids_out = manager_->getAvailableTargets();  // :78
   poses_out.assign(ids_out.size() * 7, 0.0);
   if (!ids_out.empty())

@@ -318,6 +318,29 @@ bool TargetManager::erase(unsigned id) {
   return true;
 }
 
+long TargetManager::eraseBatch(const unsigned* ids, long n) {
+  lock_guard<mutex> lg(target_lock_);
+  std::vector<std::vector<int>> slots(batches_.size());
+  std::vector<unsigned> erased;
+  for (long i = 0; i < n; ++i) {
+    Loc loc;
+    if (!find(ids[i], loc)) {     // unknown, or already taken by an earlier entry of this call
+      std::cout << "Target(" << ids[i] << ") does not exist!" << std::endl;
+      continue;
+    }
+    slots[(size_t)loc.batch].push_back(loc.slot);
+    erased.push_back(ids[i]);
+    targets_.erase(ids[i]);
+  }
+  std::vector<std::pair<unsigned, int>> moves;
+  for (size_t b = 0; b < batches_.size(); ++b) {
+    if (slots[b].empty()) continue;
+    batches_[b]->erase_slots(slots[b].data(), (long)slots[b].size(), moves);
+    for (auto const& mv : moves) targets_.set(mv.first, Loc{(int)b, mv.second});
+  }
+  return (long)erased.size();
+}
+
 bool TargetManager::getTargetPose(unsigned id, double* pose7) {
   lock_guard<mutex> lg(target_lock_);
   Loc loc;

@@ -84,6 +84,9 @@ class TargetManager {
   long initBatch(target_t type, const unsigned* ids, long n, double dt0, double t0, const double* Q, const double* R,
                  const double* P0, bool per_target_P0, const double* p0, const double* v0, const double* a0);
   long updateBatch(const unsigned* ids, long n, double dt, const double* meas, const unsigned char* has_meas);
+  // erase many targets in one call (one compaction launch per batch); unknown or repeated ids are reported
+  // like erase() does and skipped; returns the number erased
+  long eraseBatch(const unsigned* ids, long n);
   long getPoseBatch(const unsigned* ids, long n, double* pose, double* twist, double* acc, unsigned char* found,
                     bool at_time = false, double t1 = 0.0);
   long getStateBatch(const unsigned* ids, long n, double* x, double* P);

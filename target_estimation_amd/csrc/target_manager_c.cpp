@@ -166,6 +166,12 @@ int target_manager_erase(target_manager_c* self, unsigned int id) {
   return r;
 }
 
+long target_manager_erase_batch(target_manager_c* self, const unsigned int* ids, long n) {
+  long k = -1;
+  guarded("target_manager_erase_batch", [&] { k = M(self)->eraseBatch(ids, n); });
+  return k;
+}
+
 long target_manager_size(target_manager_c* self) {
   long n = -1;
   guarded("target_manager_size", [&] { n = (long)M(self)->size(); });

@@ -237,6 +237,10 @@ class TargetManager:
     def erase(self, id):
         return bool(_check(self._lib.target_manager_erase(self._h, int(id)), "target_manager_erase"))
 
+    def erase_batch(self, ids):
+        ids, idp = _ids(ids)
+        return self._lib.target_manager_erase_batch(self._h, idp, len(ids))
+
     def _get1(self, fn, id, w):
         out = np.full(w, np.nan)
         ok = fn(self._h, int(id), _dp(out))

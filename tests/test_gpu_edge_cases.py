@@ -357,3 +357,58 @@ def test_getter_table_stays_current(models, name, dtype):
             ids.append(new_id)
         check()
     mgr.close()
+
+
+def test_batched_erase_equals_one_by_one(models, capfd):
+    """target_manager_erase_batch (one compaction launch per batch) leaves every survivor exactly as erasing the
+    same ids one at a time does; unknown / repeated ids are reported and skipped; stepping continues by id."""
+    rng = np.random.default_rng(31)
+    names = ["uniform_acceleration", "angular_rates"]
+    N, dt = 500, 0.004
+    mgrs = []
+    for _ in range(2):
+        mgr = te.TargetManager(dtype="f64")
+        for k, name in enumerate(names):
+            m = models[name]
+            p0, _ = synth_stream(name, N, 2, seed=41 + k)
+            mgr.init_batch(np.arange(N, dtype=np.uint32) + 10000 * k, dt, 0.0, p0, type=m["model"], Q=m["Q"], R=m["R"], P0=m["P"])
+        mgrs.append(mgr)
+    a, b = mgrs
+    all_ids = np.concatenate([np.arange(N, dtype=np.uint32), np.arange(N, dtype=np.uint32) + 10000])
+    meas = np.tile([0.1, 0.2, 0.3, 0, 0, 0, 1.0], (len(all_ids), 1)) + rng.normal(0, 0.01, (len(all_ids), 7)) * np.array([1, 1, 1, 0, 0, 0, 0])
+    for mgr in mgrs:                                   # some history first, including the convergence gates
+        mgr.update_batch(all_ids, dt, meas)
+        mgr.intersect_converged_batch(all_ids[:50], dt, 1e-3, 1e-3, np.zeros(3), 1.0)
+    victims = rng.permutation(all_ids)[:420]
+    victims = np.concatenate([victims, victims[:3], [777777]]).astype(np.uint32)      # repeats and an unknown id
+    capfd.readouterr()
+    assert a.erase_batch(victims) == 420
+    out = capfd.readouterr().out
+    assert out.count("does not exist!") == 4 and "Target(777777) does not exist!" in out
+    for v in victims[:420]:
+        assert b.erase(int(v))
+    assert a.size() == b.size() == 2 * N - 420
+    left = np.array(a.getAvailableTargets(), dtype=np.uint32)
+    np.testing.assert_array_equal(left, np.array(b.getAvailableTargets(), dtype=np.uint32))
+    np.testing.assert_array_equal(left, np.setdiff1d(all_ids, victims))
+    rows = {int(i): j for j, i in enumerate(all_ids)}
+    for step in range(3):
+        for k in (0, 1):                               # states are per model (one state size per call)
+            sub = left[(left >= 10000) == bool(k)]
+            xa, Pa = a.get_state_batch(sub)
+            xb, Pb = b.get_state_batch(sub)
+            np.testing.assert_array_equal(xa, xb)
+            np.testing.assert_array_equal(Pa, Pb)
+        pa = a.get_est_batch(left)
+        pb = b.get_est_batch(left)
+        for u, v in zip(pa, pb):
+            np.testing.assert_array_equal(u, v)
+        sel = rng.permutation(left)[:300]
+        mm = meas[[rows[int(i)] for i in sel]]
+        assert a.update_batch(sel, dt, mm) == b.update_batch(sel, dt, mm) == 300
+    conv_a = a.intersect_converged_batch(left[:40], 3 * dt, 1e-3, 1e-3, np.zeros(3), 1.0)
+    conv_b = b.intersect_converged_batch(left[:40], 3 * dt, 1e-3, 1e-3, np.zeros(3), 1.0)
+    for u, v in zip(conv_a, conv_b):
+        np.testing.assert_array_equal(u, v)
+    assert a.erase_batch(left) == len(left) and a.size() == 0 and len(a.getAvailableTargets()) == 0
+    a.close(); b.close()
