@@ -58,6 +58,8 @@ WORKLOADS = {
     "ar1m_s201": ("1000000 targets, angular-rates model, fp32, axis-separable layout with full group blocks", "angular_rates", "f32", 1_000_000, 20240014),
     "ar1m_a90": ("1000000 targets, angular-rates model, fp32, measurements on 90 % of the (target, tick) pairs, orientation noise 0.1 rad (SURVEY 8d variant)", "angular_rates", "f32", 1_000_000, 20240018),
     "av1m_a90": ("1000000 targets, angular-velocities model, fp32, measurements on 90 % of the (target, tick) pairs, orientation noise 0.1 rad (SURVEY 8d variant)", "angular_velocities", "f32", 1_000_000, 20240019),
+    "uv1m32": ("1000000 targets, uniform-velocity model, fp32", "uniform_velocity", "f32", 1_000_000, 20240020),
+    "ua1m64": ("1000000 targets, uniform-acceleration model, fp64", "uniform_acceleration", "f64", 1_000_000, 20240021),
     "ar1m64": ("1000000 targets, angular-rates model, fp64", "angular_rates", "f64", 1_000_000, 20240016),
     "av1m64": ("1000000 targets, angular-velocities model, fp64", "angular_velocities", "f64", 1_000_000, 20240017),
 }
