@@ -412,3 +412,49 @@ def test_batched_erase_equals_one_by_one(models, capfd):
         np.testing.assert_array_equal(u, v)
     assert a.erase_batch(left) == len(left) and a.size() == 0 and len(a.getAvailableTargets()) == 0
     a.close(); b.close()
+
+
+def test_concurrent_callers_of_the_scalar_abi(models):
+    """The reference guards its manager with a mutex (target_manager.cpp:192,...); the mirror must serve several
+    threads calling the ten-symbol ABI at once (ctypes releases the GIL).  Targets are independent, so each
+    thread's targets must end exactly as in a single-threaded run of the same calls."""
+    import threading
+    name, dt, T, per, steps = "angular_velocities", 0.004, 4, 5, 60
+    p0, meas = synth_stream(name, T * per, steps, seed=51)
+
+    def drive(mgr, ids, errors):
+        try:
+            for s in range(steps):
+                for i in ids:
+                    mgr.update(i, dt, meas[s][i] if (s + i) % 7 else None)
+                    if (s + i) % 3 == 0:
+                        ok, _ = mgr.getTargetPose(i)
+                        assert ok
+        except Exception as exc:      # surfaced by the main thread
+            errors.append(exc)
+
+    results = []
+    for threaded in (False, True):
+        mgr = te.TargetManager(model_path(name))
+        for i in range(T * per):
+            mgr.init(i, dt, 0.0, p0[i])
+        groups = [list(range(k * per, (k + 1) * per)) for k in range(T)]
+        errors = []
+        if threaded:
+            th = [threading.Thread(target=drive, args=(mgr, g, errors)) for g in groups]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        else:
+            for g in groups:
+                drive(mgr, g, errors)
+        assert not errors, errors
+        ids = np.arange(T * per, dtype=np.uint32)
+        results.append((mgr.get_state_batch(ids), [mgr.getNumberMeasurements(int(i)) for i in ids]))
+        mgr.close()
+    (xa, Pa), na = results[0]
+    (xb, Pb), nb = results[1]
+    np.testing.assert_array_equal(xa, xb)
+    np.testing.assert_array_equal(Pa, Pb)
+    assert na == nb
