@@ -389,15 +389,26 @@ def parity_report(te, torch, name, n_sample=256, checkpoints=(1, 100, 1000)):
     rep = dict(targets=n_sample, layout=b.layout, ticks=list(checkpoints), max_abs_x=[], max_rel_x=[], max_rel_P=[],
                ids_exact=bool((b.slot_ids() == ids).all()), oracle="oracle/te_oracle.c, same precision (%s)" % dtype,
                tolerance=("x: 1e-10 + 1e-10|x|, P: 1e-9 max|P|" if dtype == "f64" else "x: 2e-3 + 1e-4|x|, P: 2e-3 max|P|"))
+    # an fp32 batch is also compared with the fp64 oracle: the end-to-end precision loss
+    orc64 = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], p0, dt, dtype="f64") if dtype == "f32" else None
+    if orc64 is not None:
+        rep["vs_f64_oracle"] = dict(max_abs_x=[], max_rel_P=[])
     for s in range(ticks):
         b.step(dt, meas[s])
-        orc.step(dt, np.ascontiguousarray(meas_host[s].T))
+        row = np.ascontiguousarray(meas_host[s].T)
+        orc.step(dt, row)
+        if orc64 is not None:
+            orc64.step(dt, row)
         if s + 1 in checkpoints:
             x, P = mgr.get_state_batch(ids)
             xo, Po = orc.state()
             rep["max_abs_x"].append(float(np.abs(x - xo).max()))
             rep["max_rel_x"].append(float((np.abs(x - xo) / np.maximum(np.abs(xo), 1e-3)).max()))
             rep["max_rel_P"].append(float((np.abs(P - Po) / np.abs(Po).max(axis=(1, 2), keepdims=True)).max()))
+            if orc64 is not None:
+                x64, P64 = orc64.state()
+                rep["vs_f64_oracle"]["max_abs_x"].append(float(np.abs(x - x64).max()))
+                rep["vs_f64_oracle"]["max_rel_P"].append(float((np.abs(P - P64) / np.abs(P64).max(axis=(1, 2), keepdims=True)).max()))
     mgr.close()
     return rep
 
