@@ -31,6 +31,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 # reference's rounding-level asymmetry of P); *_full / *_packed force the dense kernel (what general matrices
 # get): full P, or symmetric-packed P (101 = 1 + TARGET_LAYOUT_SYMMETRIC_PACKED).
 TUNED_LANES = {"cfg2_full": 3, "uv1m_full": 1, "ua1m_full": 1, "ar1m_full": 6, "av1m_full": 3, "uv1m_packed": 101,
+               "ar1m_packed": 103, "av1m_packed": 101,   # what coupled but symmetric Q, R, P0 get automatically
                "uv1m_s201": 201, "ua1m_s201": 201, "av1m_s201": 201, "ar1m_s201": 201}
 
 # stream variants: availability < 1 = per-(target, tick) measurement mask (predict-only otherwise); rpy_noise = orientation noise
@@ -49,6 +50,8 @@ WORKLOADS = {
     "cfg2_full": ("10000 targets, uniform-velocity model, fp64, dense kernel with full P", "uniform_velocity", "f64", 10_000, 20240002),
     "uv1m_full": ("1000000 targets, uniform-velocity model, fp64, dense kernel with full P", "uniform_velocity", "f64", 1_000_000, 20240012),
     "uv1m_packed": ("1000000 targets, uniform-velocity model, fp64, dense kernel with symmetric-packed P", "uniform_velocity", "f64", 1_000_000, 20240012),
+    "ar1m_packed": ("1000000 targets, angular-rates model, fp32, dense kernel with symmetric-packed P, 3 lanes per target", "angular_rates", "f32", 1_000_000, 20240014),
+    "av1m_packed": ("1000000 targets, angular-velocities model, fp32, dense kernel with symmetric-packed P", "angular_velocities", "f32", 1_000_000, 20240015),
     "ua1m_full": ("1000000 targets, uniform-acceleration model, fp32, dense kernel with full P", "uniform_acceleration", "f32", 1_000_000, 20240013),
     "ar1m_full": ("1000000 targets, angular-rates model, fp32, dense kernel with full P", "angular_rates", "f32", 1_000_000, 20240014),
     "av1m_full": ("1000000 targets, angular-velocities model, fp32, dense kernel with full P", "angular_velocities", "f32", 1_000_000, 20240015),
@@ -453,7 +456,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + sorted(MIXED))
     ap.add_argument("--lanes", type=int, default=0, help="lanes per target (0 = tuned default)")
     ap.add_argument("--targets", type=int, default=0, help="override targets per GPU")
-    ap.add_argument("--extra", default="cfg3,cfg4,cfg5,cfg4x8,cfg5x8,uv1m,ua1m,av1m,ar1m,ar1m_a90,av1m_a90,ar1m_s201,av1m_s201,cfg2_full,uv1m_full,uv1m_packed,ar1m_full", help="comma list of extra workloads reported under 'extra' (N=1 only; '' = none)")
+    ap.add_argument("--extra", default="cfg3,cfg4,cfg5,cfg4x8,cfg5x8,uv1m,ua1m,av1m,ar1m,ar1m_a90,av1m_a90,ar1m_s201,av1m_s201,cfg2_full,uv1m_full,uv1m_packed,ar1m_full,ar1m_packed", help="comma list of extra workloads reported under 'extra' (N=1 only; '' = none)")
     ap.add_argument("--extra-multi", default="uv1m,ua1m,av1m,ar1m,cfg4,cfg5",
                     help="extra workloads when --gpus > 1 (per-GPU sizes; every rank runs them in lockstep)")
     ap.add_argument("--extra-steps", type=int, default=50)

@@ -23,7 +23,7 @@ typedef void target_batch_c; /* all targets of one (model, Q, R) inside a manage
 #define TARGET_ANGULAR_VELOCITIES 1
 #define TARGET_UNIFORM_ACCELERATION 2
 #define TARGET_UNIFORM_VELOCITY 3
-/* add to lanes_per_target = 1 to store P symmetric-packed (upper triangle) in HBM */
+/* add to lanes_per_target (1, 2, 3 or 6) to store P symmetric-packed (upper triangle) in HBM */
 #define TARGET_LAYOUT_SYMMETRIC_PACKED 100
 /* lanes_per_target = 1 + this: store only the entries of P inside an axis group (exact when Q, R and
  * P0 do not couple different axes, as in every shipped model file; refused otherwise) */
@@ -40,12 +40,15 @@ extern "C" {
 /* ---- construction ---------------------------------------------------------------------- */
 /* file may be NULL (no default model: use the *_typed initialisers, as the reference's
  * default-constructed TargetManager, target_manager.cpp:106-109).  dtype: TARGET_DTYPE_*.
- * lanes_per_target: 0 = automatic, checked per init call: when Q, R and P0 do not couple different axis
- * groups, the axis-separable layout -- with each group block stored as its upper triangle
- * (1 + TARGET_LAYOUT_AXIS_SEPARABLE_PACKED) when the matrices are also exactly symmetric, with full
- * group blocks (1 + TARGET_LAYOUT_AXIS_SEPARABLE) otherwise -- else the tuned dense default for
- * (model, dtype).  Explicit: 1, 2, 3 or 6 (dense, full P), 1 + TARGET_LAYOUT_SYMMETRIC_PACKED (dense,
- * thread per target, upper triangle of P only in HBM: 45 % less traffic), or one of the two separable
+ * lanes_per_target: 0 = automatic, checked per init call:
+ *   - Q, R and P0 do not couple different axis groups: the axis-separable layout -- with each group block
+ *     stored as its upper triangle (1 + TARGET_LAYOUT_AXIS_SEPARABLE_PACKED) when the matrices are also
+ *     exactly symmetric, with full group blocks (1 + TARGET_LAYOUT_AXIS_SEPARABLE) otherwise;
+ *   - coupled but exactly symmetric: the dense kernel on the upper triangle of P
+ *     (G + TARGET_LAYOUT_SYMMETRIC_PACKED, G = lanes per target: 1 or 3 depending on the model);
+ *   - anything else: the dense kernel on the full P with the tuned G of (model, dtype).
+ * Explicit: 1, 2, 3 or 6 (dense, full P), G + TARGET_LAYOUT_SYMMETRIC_PACKED with G = 1, 2, 3 or 6 where
+ * the model allows it (upper triangle of P only in HBM: 44 % less traffic), or one of the two separable
  * codes.  With a packed layout P is symmetric by construction, whereas the reference's (I-KC)P is
  * symmetric only to rounding; the full layouts reproduce that rounding-level asymmetry (the
  * axis-separable full-block layout is bit-identical to the dense kernel). */

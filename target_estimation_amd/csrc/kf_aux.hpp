@@ -14,7 +14,7 @@ namespace te {
 template <class C, typename T>
 __device__ __forceinline__ T* state_ptr(char* rec, long slot, int r, int c) {
   const long tile = slot / C::TPW;
-  const int lane = (int)(slot % C::TPW) * C::G + (r % C::G);
+  const int lane = (int)(slot % C::TPW) * C::G + ((c >= C::N) ? (r % C::G) : C::p_lane(r, c));
   const int q = (r % C::K) / C::G + (r / C::K) * C::KPL;
   const int w = (c >= C::N) ? C::X_OFF + q : C::p_word(r, c);
   if (w < 0) return nullptr;

@@ -9,6 +9,8 @@ const Ops* get_ops_av(int dtype, int g) {
     switch (g) {
       case 3: return OpsImpl<ModelAV, double, 3>::get();
       case 6: return OpsImpl<ModelAV, double, 6>::get();
+      case 103: return OpsImpl<ModelAV, double, 3, LAYOUT_PACKED>::get();  // symmetric-packed P, 3 lanes per target
+      case 106: return OpsImpl<ModelAV, double, 6, LAYOUT_PACKED>::get();  // symmetric-packed P, 6 lanes per target
       case 201: return OpsImpl<ModelAV, double, 1, LAYOUT_SEPARABLE>::get();  // axis-separable
       case 301: return OpsImpl<ModelAV, double, 1, LAYOUT_SEPARABLE_PACKED>::get();  // + symmetric-packed groups
       default: return nullptr;
@@ -20,6 +22,8 @@ const Ops* get_ops_av(int dtype, int g) {
       case 101: return OpsImpl<ModelAV, float, 1, LAYOUT_PACKED>::get();  // symmetric-packed P
       case 3: return OpsImpl<ModelAV, float, 3>::get();
       case 6: return OpsImpl<ModelAV, float, 6>::get();
+      case 103: return OpsImpl<ModelAV, float, 3, LAYOUT_PACKED>::get();  // symmetric-packed P, 3 lanes per target
+      case 106: return OpsImpl<ModelAV, float, 6, LAYOUT_PACKED>::get();  // symmetric-packed P, 6 lanes per target
       case 201: return OpsImpl<ModelAV, float, 1, LAYOUT_SEPARABLE>::get();  // axis-separable
       case 301: return OpsImpl<ModelAV, float, 1, LAYOUT_SEPARABLE_PACKED>::get();  // + symmetric-packed groups
       default: return nullptr;

@@ -10,6 +10,7 @@ const Ops* get_ops_ua(int dtype, int g) {
       case 1: return OpsImpl<ModelUA, double, 1>::get();
       case 101: return OpsImpl<ModelUA, double, 1, LAYOUT_PACKED>::get();  // symmetric-packed P
       case 3: return OpsImpl<ModelUA, double, 3>::get();
+      case 103: return OpsImpl<ModelUA, double, 3, LAYOUT_PACKED>::get();  // symmetric-packed P, 3 lanes per target
       case 201: return OpsImpl<ModelUA, double, 1, LAYOUT_SEPARABLE>::get();  // axis-separable
       case 301: return OpsImpl<ModelUA, double, 1, LAYOUT_SEPARABLE_PACKED>::get();  // + symmetric-packed groups
       default: return nullptr;
@@ -20,6 +21,7 @@ const Ops* get_ops_ua(int dtype, int g) {
       case 1: return OpsImpl<ModelUA, float, 1>::get();
       case 101: return OpsImpl<ModelUA, float, 1, LAYOUT_PACKED>::get();  // symmetric-packed P
       case 3: return OpsImpl<ModelUA, float, 3>::get();
+      case 103: return OpsImpl<ModelUA, float, 3, LAYOUT_PACKED>::get();  // symmetric-packed P, 3 lanes per target
       case 201: return OpsImpl<ModelUA, float, 1, LAYOUT_SEPARABLE>::get();  // axis-separable
       case 301: return OpsImpl<ModelUA, float, 1, LAYOUT_SEPARABLE_PACKED>::get();  // + symmetric-packed groups
       default: return nullptr;

@@ -151,12 +151,58 @@ __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kern
   wave_lds_fence();
   const T* sQ = sQw;
   const T* sR = sQw + N * N;
+  // per-wave LDS scratch: element `idx` of this lane's target at [idx*GS + g]
+  T* sx = s_ex + (C::EX_WORDS > 0 ? C::EX_WORDS : 1) * wave;
+#define EXA_(idx) sx[(idx) * GS + g]
+#define EXB_(idx) sx[(C::EXA + (idx)) * GS + g]
+#define EXC_(idx) sx[(C::EXA + C::EXB + (idx)) * GS + g]
+#define EXP_(idx) sx[(idx) * GS + g]   /* aliases EXA/EXB/EXC: used only outside the predict/update section */
+
   T rec[C::FRW];
-  if constexpr (PK) {
+  // packed with G > 1: the triangle passes through the wave's LDS scratch.  Row r = i + G q of this lane;
+  // element (r, c) of the triangle is tri(r, c) = tri_base[q] + c for c >= r, tri(c, r) = tri_col(c) + r below.
+  int tri_base[RPL];
+#pragma unroll
+  for (int q = 0; q < RPL; ++q) {
+    const int r = i + G * q;
+    tri_base[q] = r * N - r * (r - 1) / 2 - r;
+  }
+  auto rows_from_lds = [&]() {   // gather the full rows of this lane from the triangle in LDS
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) {
+      const int r = i + G * q;
+#pragma unroll
+      for (int c = 0; c < N; ++c) {
+        const int idx = (c >= r) ? tri_base[q] + c : (c * N - c * (c - 1) / 2 - c) + r;
+        rec[q * N + c] = EXP_(idx);
+      }
+    }
+  };
+  auto rows_to_lds = [&]() {     // scatter the upper part (c >= r) of this lane's rows into the triangle
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) {
+      const int r = i + G * q;
+#pragma unroll
+      for (int c = 0; c < N; ++c)
+        if (c >= r) EXP_(tri_base[q] + c) = rec[q * N + c];
+    }
+  };
+  if constexpr (PK && G == 1) {
 #pragma unroll
     for (int r = 0; r < N; ++r)
 #pragma unroll
       for (int c = 0; c < N; ++c) rec[r * N + c] = mem[r <= c ? C::tri(r, c) : C::tri(c, r)];
+#pragma unroll
+    for (int w = 0; w < RPL + C::UW; ++w) rec[RPL * N + w] = mem[C::X_OFF + w];
+  } else if constexpr (PK) {
+#pragma unroll
+    for (int k = 0; k < C::PW; ++k) {
+      const int t = i * C::PW + k;
+      if (t < C::TRI) EXP_(t) = mem[k];
+    }
+    wave_lds_fence();
+    rows_from_lds();
+    wave_lds_fence();
 #pragma unroll
     for (int w = 0; w < RPL + C::UW; ++w) rec[RPL * N + w] = mem[C::X_OFF + w];
   } else {
@@ -167,12 +213,6 @@ __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kern
 #define P_(q, c) rec[(q) * N + (c)]
 #define X_(q) rec[RPL * N + (q)]
 #define UW_(s) rec[RPL * N + RPL + (s)]
-
-  // per-wave LDS scratch: element `idx` of this lane's target at [idx*GS + g]
-  T* sx = s_ex + (C::EX_WORDS > 0 ? C::EX_WORDS : 1) * wave;
-#define EXA_(idx) sx[(idx) * GS + g]
-#define EXB_(idx) sx[(C::EXA + (idx)) * GS + g]
-#define EXC_(idx) sx[(C::EXA + C::EXB + (idx)) * GS + g]
 
   double dtd = a.dt;
   if constexpr (INDEXED) {
@@ -510,14 +550,36 @@ __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kern
 
   if constexpr (FUSED && PK) {
     // a packed batch re-symmetrises P every tick (store upper triangle, reload mirrored)
+    if constexpr (G == 1) {
 #pragma unroll
-    for (int r = 0; r < N; ++r)
+      for (int r = 0; r < N; ++r)
 #pragma unroll
-      for (int c = r + 1; c < N; ++c) rec[c * N + r] = rec[r * N + c];
+        for (int c = r + 1; c < N; ++c) rec[c * N + r] = rec[r * N + c];
+    } else {
+      wave_lds_fence();
+      rows_to_lds();
+      wave_lds_fence();
+      rows_from_lds();
+      wave_lds_fence();
+    }
   }
   }  // tick loop
+  if constexpr (PK && G > 1) {   // all lanes of the wave take part in the transposition
+    wave_lds_fence();
+    rows_to_lds();
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < C::PW; ++k) {
+      const int t = i * C::PW + k;
+      mem[k] = (t < C::TRI) ? EXP_(t) : (T)0;
+    }
+#pragma unroll
+    for (int w = 0; w < RPL + C::UW; ++w) mem[C::X_OFF + w] = rec[RPL * N + w];
+  }
   if (valid) {
-    if constexpr (PK) {
+    if constexpr (PK && G > 1) {
+      // mem was filled above
+    } else if constexpr (PK) {
 #pragma unroll
       for (int r = 0; r < N; ++r)
 #pragma unroll
@@ -545,6 +607,7 @@ __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kern
 #undef EXA_
 #undef EXB_
 #undef EXC_
+#undef EXP_
 }
 
 }  // namespace te

@@ -122,7 +122,18 @@ int TargetManager::chooseLayout(int type, const double* Q, const double* R, cons
   const bool sep = is_axis_separable(type, Q, R, P0, n_P0);
   // automatic: the smallest record the matrices allow -- per-axis-group blocks when nothing couples the
   // groups, their upper triangles only when everything is symmetric as well
-  if (lanes_ == 0) return !sep ? 0 : (all_symmetric(type, Q, R, P0, n_P0) ? kSeparablePacked : kSeparable);
+  if (lanes_ == 0) {
+    const bool sym = all_symmetric(type, Q, R, P0, n_P0);
+    if (sep) return sym ? kSeparablePacked : kSeparable;
+    if (!sym) return 0;   // general matrices: dense kernel, full P, tuned lanes per target
+    // coupled but symmetric: dense kernel on the upper triangle (100 + lanes per target), the fastest
+    // packed form of each (model, precision) at 10^6 targets (tools/sweep.py)
+    switch (type) {
+      case ANGULAR_RATES: return 103;
+      case ANGULAR_VELOCITIES: return dtype_ == F32 ? 101 : 103;
+      default: return 101;
+    }
+  }
   if ((lanes_ == kSeparable || lanes_ == kSeparablePacked) && !sep)
     throw std::runtime_error("target_estimation_amd: the axis-separable layout was requested but Q, R or P0 couple different axes");
   return lanes_;

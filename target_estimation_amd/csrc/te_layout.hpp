@@ -48,10 +48,12 @@ enum Layout : int { LAYOUT_FULL = 0, LAYOUT_PACKED = 1, LAYOUT_SEPARABLE = 2, LA
 constexpr int model_n(int type) { return type == UNIFORM_VELOCITY ? 6 : type == UNIFORM_ACCELERATION ? 9 : type == ANGULAR_RATES ? 18 : 12; }
 constexpr int model_m(int type) { return (type == UNIFORM_VELOCITY || type == UNIFORM_ACCELERATION) ? 3 : 6; }
 
-// PK_ = symmetric-packed storage: only the upper triangle of P (r <= c, row-major) is kept in HBM
-// and mirrored into the registers after the load.  Offered for G = 1 (thread per target), where
-// the mirror is a register rename.  The reference's (I-KC)P is symmetric only to rounding
-// (~1e-16 relative); packed batches keep the owner-row value P[r][c], r <= c, of each pair.
+// PK_ = symmetric-packed storage: only the upper triangle of P (r <= c, row-major, N(N+1)/2 words) is
+// kept in HBM.  G = 1 (thread per target): the mirror into the registers is a register rename.
+// G > 1: lane i of a target stores the i-th slice of ceil(N(N+1)/2 / G) words of the triangle; after
+// the load the wavefront puts the triangle into its LDS scratch and every lane gathers its full rows
+// from there (and the reverse before the store).  The reference's (I-KC)P is symmetric only to
+// rounding (~1e-16 relative); packed batches keep the owner-row value P[r][c], r <= c, of each pair.
 // LAYOUT_SEPARABLE: only the entries of P inside an axis group are stored (the others are
 // structurally zero); thread per target, dedicated kernel (kf_step_sep.hpp).
 template <class M, typename T, int G_, int LAYOUT_ = LAYOUT_FULL>
@@ -61,7 +63,7 @@ struct Cfg {
   static constexpr bool PK = LAYOUT_ == LAYOUT_PACKED;
   static constexpr bool SEP = LAYOUT_ == LAYOUT_SEPARABLE || LAYOUT_ == LAYOUT_SEPARABLE_PACKED;
   static constexpr bool SEPPK = LAYOUT_ == LAYOUT_SEPARABLE_PACKED;   // group blocks stored as upper triangles
-  static_assert(LAYOUT_ == LAYOUT_FULL || G_ == 1, "packed / separable storage use the thread-per-target mapping");
+  static_assert(!(LAYOUT_ == LAYOUT_SEPARABLE || LAYOUT_ == LAYOUT_SEPARABLE_PACKED) || G_ == 1, "separable storage uses the thread-per-target mapping");
   static constexpr int N = M::N, K = M::K, NB = M::NB;
   static_assert(K % G == 0, "lanes per target must divide the block size");
   static constexpr int RPL = N / G;           // rows of x / P per lane
@@ -75,7 +77,8 @@ struct Cfg {
       for (int c = (LAYOUT_ == LAYOUT_SEPARABLE_PACKED ? r : 0); c < M::N; ++c) k += group_of(M::TYPE, r) == group_of(M::TYPE, c) ? 1 : 0;
     return k;
   }
-  static constexpr int PW = SEP ? sep_count() : PK ? N * (N + 1) / 2 : RPL * N;   // words of P per lane in HBM
+  static constexpr int TRI = N * (N + 1) / 2;                  // words of the upper triangle
+  static constexpr int PW = SEP ? sep_count() : PK ? (TRI + G - 1) / G : RPL * N;   // words of P per lane in HBM
   static constexpr int RW = PW + RPL + UW;                     // record words per lane in HBM
   static constexpr int FRW = RPL * (N + 1) + UW;               // words of the full register image
   static constexpr int VW = 16 / (int)sizeof(T);               // words per 16-byte chunk
@@ -106,17 +109,25 @@ struct Cfg {
         }
       return -1;
     }
-    if (PK) return r <= c ? tri(r, c) : tri(c, r);
+    if (PK) return (r <= c ? tri(r, c) : tri(c, r)) % PW;
     return ((r % K) / G + (r / K) * KPL) * N + c;
+  }
+  // which of the G lanes of a target holds P(r, c)
+  static constexpr int p_lane(int r, int c) {
+    if (PK) return (r <= c ? tri(r, c) : tri(c, r)) / PW;
+    return r % G;
   }
   // LDS exchange words per target (G > 1 only)
   static constexpr int EXA = K * N;                 // top rows of P^- (AV: also the 6 mid rows)
   static constexpr int EXB = K * K;                 // S^-1
   static constexpr int EXC = M::EKF ? N : K;        // pivot row / innovation (EKF: x exchange)
+  // the packed triangle while it is transposed (G > 1); it aliases the exchange areas above, which are
+  // only live inside the predict/update section
+  static constexpr int EXP = (PK && G > 1) ? TRI : 0;
   // LDS column stride: one spare column so that the idle lanes (>= LPT) of a wave, whose group
   // index is TPW, never alias a live target's scratch
   static constexpr int GS = (64 + G - 1) / G;
-  static constexpr int EX_WORDS = (G == 1) ? 0 : GS * (EXA + EXB + EXC);
+  static constexpr int EX_WORDS = (G == 1) ? 0 : GS * ((EXA + EXB + EXC) > EXP ? (EXA + EXB + EXC) : EXP);
   // p_word as a compile-time table (so that fully unrolled kernels index registers statically)
   struct WordTable { int v[N][N]; };
   static constexpr WordTable make_table() {

@@ -47,10 +47,19 @@ void check_layout(const char* name) {
       if (w < 0) { CHECK(C::SEP && group_of(M::TYPE, r) != group_of(M::TYPE, c)); continue; }
       CHECK(w < C::PW);
       ++stored;
-      if (LAYOUT == LAYOUT_PACKED || LAYOUT == LAYOUT_SEPARABLE_PACKED) { CHECK(w == C::p_word(c, r)); continue; }
+      if (LAYOUT == LAYOUT_PACKED || LAYOUT == LAYOUT_SEPARABLE_PACKED) {
+        CHECK(w == C::p_word(c, r) && C::p_lane(r, c) == C::p_lane(c, r) && C::p_lane(r, c) >= 0 && C::p_lane(r, c) < G);
+        continue;
+      }
       CHECK(words[r % G].insert(w).second);
     }
   if (LAYOUT == LAYOUT_FULL) CHECK(stored == C::N * C::N);
+  if (LAYOUT == LAYOUT_PACKED) {   // the G lanes of a target hold the upper triangle exactly once, in slices of PW words
+    std::set<std::pair<int, int>> cells;
+    for (int r = 0; r < C::N; ++r)
+      for (int c = r; c < C::N; ++c) CHECK(cells.insert({C::p_lane(r, c), C::p_word(r, c)}).second);
+    CHECK((int)cells.size() == C::TRI && C::PW * G >= C::TRI && C::PW * G < C::TRI + G);
+  }
   if (LAYOUT == LAYOUT_SEPARABLE) CHECK(stored == C::PW);
   if (LAYOUT == LAYOUT_SEPARABLE_PACKED) CHECK(stored == 2 * C::PW - C::N);
   CHECK(C::X_OFF == C::PW && C::UW_OFF == C::PW + C::RPL && C::RW == C::PW + C::RPL + C::UW);
@@ -111,6 +120,13 @@ int main(int argc, char** argv) {
   check_layout<ModelUV, float, 3, LAYOUT_FULL>("UV f32 G3 full");
   check_layout<ModelUV, float, 1, LAYOUT_PACKED>("UV f32 G1 packed");
   check_layout<ModelUV, double, 1, LAYOUT_SEPARABLE>("UV f64 separable");
+  check_layout<ModelUV, double, 3, LAYOUT_PACKED>("UV f64 G3 packed");
+  check_layout<ModelUA, float, 3, LAYOUT_PACKED>("UA f32 G3 packed");
+  check_layout<ModelAV, double, 3, LAYOUT_PACKED>("AV f64 G3 packed");
+  check_layout<ModelAV, float, 6, LAYOUT_PACKED>("AV f32 G6 packed");
+  check_layout<ModelAR, float, 2, LAYOUT_PACKED>("AR f32 G2 packed");
+  check_layout<ModelAR, float, 3, LAYOUT_PACKED>("AR f32 G3 packed");
+  check_layout<ModelAR, double, 6, LAYOUT_PACKED>("AR f64 G6 packed");
   check_layout<ModelUA, float, 1, LAYOUT_FULL>("UA f32 G1 full");
   check_layout<ModelUA, double, 3, LAYOUT_FULL>("UA f64 G3 full");
   check_layout<ModelUA, double, 1, LAYOUT_PACKED>("UA f64 G1 packed");

@@ -24,11 +24,12 @@ TOL = {"f64": dict(x_atol=1e-10, x_rtol=1e-10, P_rel=1e-9, out_atol=1e-9),
 # 101 = thread per target with symmetric-packed P in HBM (1 + TARGET_LAYOUT_SYMMETRIC_PACKED);
 # 201 = axis-separable layout (1 + TARGET_LAYOUT_AXIS_SEPARABLE); 0 = automatic (separable here,
 # because the shipped Q, R, P0 do not couple axes)
-LANES = {"uniform_velocity": {"f64": [0, 1, 3, 101, 201, 301], "f32": [1, 3, 101, 201, 301]},
-         "uniform_acceleration": {"f64": [0, 1, 3, 101, 201, 301], "f32": [1, 3, 101, 201, 301]},
-         "angular_rates": {"f64": [0, 3, 6, 201, 301], "f32": [2, 3, 6, 201, 301]},
-         "angular_velocities": {"f64": [0, 3, 6, 201, 301], "f32": [1, 3, 6, 101, 201, 301]}}
-LAYOUT_OF = {0: "axis_separable_packed", 101: "symmetric_packed", 201: "axis_separable", 301: "axis_separable_packed"}
+LANES = {"uniform_velocity": {"f64": [0, 1, 3, 101, 103, 201, 301], "f32": [1, 3, 101, 103, 201, 301]},
+         "uniform_acceleration": {"f64": [0, 1, 3, 101, 103, 201, 301], "f32": [1, 3, 101, 103, 201, 301]},
+         "angular_rates": {"f64": [0, 3, 6, 103, 106, 201, 301], "f32": [2, 3, 6, 102, 103, 106, 201, 301]},
+         "angular_velocities": {"f64": [0, 3, 6, 103, 106, 201, 301], "f32": [1, 3, 6, 101, 103, 106, 201, 301]}}
+LAYOUT_OF = {0: "axis_separable_packed", 101: "symmetric_packed", 102: "symmetric_packed", 103: "symmetric_packed",
+             106: "symmetric_packed", 201: "axis_separable", 301: "axis_separable_packed"}
 CASES = [(m, d, g) for m in HARNESS_ORDER for d in ("f64", "f32") for g in LANES[m][d]]
 
 
@@ -117,26 +118,30 @@ def coupled(m, seed=3):
 
 @pytest.mark.parametrize("name,dtype", [(m, d) for m in HARNESS_ORDER for d in ("f64", "f32")])
 def test_general_matrices_use_the_dense_kernel(models, name, dtype):
-    """With Q, R, P0 that couple the axes the automatic layout must fall back to the dense kernel
-    (and the separable layout must be refused); parity as for the shipped models."""
+    """With Q, R, P0 that couple the axes the automatic layout must fall back to the dense kernel (and the
+    separable layout must be refused): on the upper triangle when the matrices are symmetric, on the full P
+    when they are not; parity as for the shipped models."""
     m = models[name]
     cm = coupled(m)
     N, steps, dt = 150, 40, 0.004
     p0, meas = synth_stream(name, N, steps, seed=13)
     ids = np.arange(N, dtype=np.uint32)
-    mgr = te.TargetManager(dtype=dtype)                       # no default model: typed init
-    mgr.init_batch(ids, dt, 0.0, p0, type=m["model"], Q=cm["Q"], R=cm["R"], P0=cm["P"])
-    b = mgr.batches()[0]
-    assert b.layout == "full"
-    orc = oracle.OracleBatch(m["model"], cm["Q"], cm["R"], cm["P"], p0, dt, dtype=dtype)
-    for s in range(steps):
-        b.step(dt, to_soa(meas[s], b))
-        orc.step(dt, meas[s])
-    check_state(mgr, ids, orc, dtype, "coupled %s" % name)
-    _, P = mgr.get_state_batch(ids[:3])
-    n = P.shape[1]
-    assert np.abs(P[0][0, 1]) > 0 and np.abs(P[0][1, n - 1]) > 0     # really dense
-    mgr.close()
+    P_asym = cm["P"].copy()
+    P_asym[0, 1] *= 0.5                                       # a valid input for the reference: any matrix goes
+    for P0, want in ((cm["P"], "symmetric_packed"), (P_asym, "full")):
+        mgr = te.TargetManager(dtype=dtype)                   # no default model: typed init
+        mgr.init_batch(ids, dt, 0.0, p0, type=m["model"], Q=cm["Q"], R=cm["R"], P0=P0)
+        b = mgr.batches()[0]
+        assert b.layout == want
+        orc = oracle.OracleBatch(m["model"], cm["Q"], cm["R"], P0, p0, dt, dtype=dtype)
+        for s in range(steps):
+            b.step(dt, to_soa(meas[s], b))
+            orc.step(dt, meas[s])
+        check_state(mgr, ids, orc, dtype, "coupled %s %s" % (name, want))
+        _, P = mgr.get_state_batch(ids[:3])
+        n = P.shape[1]
+        assert np.abs(P[0][0, 1]) > 0 and np.abs(P[0][1, n - 1]) > 0     # really dense
+        mgr.close()
     sep = te.TargetManager(dtype=dtype, lanes_per_target=201)
     with pytest.raises(RuntimeError, match="couple different axes"):
         sep.init_batch(ids, dt, 0.0, p0, type=m["model"], Q=cm["Q"], R=cm["R"], P0=cm["P"])
