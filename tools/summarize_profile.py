@@ -50,7 +50,7 @@ def main():
     print("# rocprofv3 summary of %s (kernels matching '%s')" % (os.path.basename(d.rstrip("/")), flt))
     print("# durations: --kernel-trace; bytes: --pmc FETCH_SIZE / WRITE_SIZE (separate passes)")
     print("# hbm_read = 2 * FETCH_SIZE * 1024 (gfx950 wide-stream correction), hbm_write = WRITE_SIZE * 1024")
-    print("%-52s %9s %6s %10s %10s %10s %12s %12s" % ("kernel", "grid", "calls", "avg_us", "min_us", "max_us", "hbm_rd_MB", "hbm_wr_MB"))
+    print("%-66s %9s %6s %10s %10s %10s %12s %12s" % ("kernel", "grid", "calls", "avg_us", "min_us", "max_us", "hbm_rd_MB", "hbm_wr_MB"))
     for (k, g), durs in sorted(trace.items(), key=lambda kv: -sum(kv[1])):
         if flt not in k:
             continue
@@ -58,7 +58,7 @@ def main():
         ws = counters.get((k, g, "WRITE_SIZE"))
         rd = "%12.3f" % (2 * 1024 * sum(fs) / len(fs) / 1e6) if fs else "%12s" % "-"
         wr = "%12.3f" % (1024 * sum(ws) / len(ws) / 1e6) if ws else "%12s" % "-"
-        print("%-52s %9d %6d %10.2f %10.2f %10.2f %s %s" % (k[:52], g, len(durs), sum(durs) / len(durs) / 1e3,
+        print("%-66s %9d %6d %10.2f %10.2f %10.2f %s %s" % (k[:66], g, len(durs), sum(durs) / len(durs) / 1e3,
                                                          min(durs) / 1e3, max(durs) / 1e3, rd, wr))
     for tag in ("trace", "fetch", "write"):
         p = os.path.join(d, "bench_%s.json" % tag)
