@@ -457,8 +457,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="lanes per target (0 = tuned default)")
     ap.add_argument("--targets", type=int, default=0, help="override targets per GPU")
     ap.add_argument("--extra", default="cfg3,cfg4,cfg5,cfg4x8,cfg5x8,uv1m,ua1m,av1m,ar1m,ar1m_a90,av1m_a90,ar1m_s201,av1m_s201,cfg2_full,uv1m_full,uv1m_packed,ar1m_full,ar1m_packed", help="comma list of extra workloads reported under 'extra' (N=1 only; '' = none)")
-    ap.add_argument("--extra-multi", default="uv1m,ua1m,av1m,ar1m,cfg4,cfg5",
-                    help="extra workloads when --gpus > 1 (per-GPU sizes; every rank runs them in lockstep)")
+    ap.add_argument("--extra-multi", default="uv1m,ua1m,av1m,ar1m,cfg4,cfg5,uv1m_strong,ar1m_strong",
+                    help="extra workloads when --gpus > 1 (per-GPU sizes; every rank runs them in lockstep; NAME_strong = the workload's "
+                         "targets split over the ranks)")
     ap.add_argument("--extra-steps", type=int, default=50)
     ap.add_argument("--scale", type=int, default=1, help="mixed workloads (cfg4/cfg5): multiply the per-GPU populations (8 = all 10^6 targets on one GPU)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -565,6 +566,14 @@ def main():
             r["name"] = name
             if sc > 1:
                 r["desc"] += " -- x%d: the whole population on this GPU" % sc
+        elif name.endswith("_strong"):                  # strong scaling: the workload's targets split over the ranks
+            wl = name[:-len("_strong")]
+            per_rank = WORKLOADS[wl][3] // world
+            r = run_workload(te, torch, wl, args.extra_steps if per_rank > 200000 else 640, 10, 0, targets=per_rank,
+                             dist=dist, rank=rank, world=world, launch_mode=args.launch_mode)
+            r.pop("_mgr")
+            r["name"] = name
+            r["desc"] += " -- strong scaling: %d targets in total, %d per GPU" % (per_rank * world, per_rank)
         else:
             small = WORKLOADS[name][3] <= 200000
             r = run_workload(te, torch, name, 1920 if small else args.extra_steps, 64 if small else 10, 0,
