@@ -27,3 +27,21 @@ def test_plain_c_caller_of_the_ten_symbols(tmp_path):
     assert "drop-in test ok" in out.stdout
     assert "Target(7) already exists!" in out.stdout
     assert "Target(8) does not exist!" in out.stdout
+
+
+def test_cpp_example_of_the_batch_api(tmp_path):
+    """examples/batched_replay.cpp: the device-resident batch API driven from plain C++ (hipcc, no Python)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    libdir = os.path.join(ROOT, "target_estimation_amd", "lib")
+    exe = str(tmp_path / "batched_replay")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-w",
+                           "-I", os.path.join(ROOT, "include", "target_estimation_amd"),
+                           os.path.join(ROOT, "examples", "batched_replay.cpp"), "-o", exe,
+                           "-L", libdir, "-ltarget_estimation_amd", "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe, model_path("angular_velocities"), "5000", "256"], capture_output=True, text=True, timeout=300)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "5000 targets, 256 ticks" in out.stdout and "predict+update cycles/s" in out.stdout
+    assert "384 measurements" in out.stdout          # 256 timed + 4 warm-up blocks of 32 ticks
