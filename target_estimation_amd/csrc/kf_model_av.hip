@@ -5,7 +5,7 @@ namespace te {
 
 const Ops* get_ops_av(int dtype, int g) {
   if (dtype == F64) {
-    if (g == 0) g = 6;
+    if (g == 0) g = 3;   // profiles/r01_layout_sweep.txt
     switch (g) {
       case 3: return OpsImpl<ModelAV, double, 3>::get();
       case 6: return OpsImpl<ModelAV, double, 6>::get();
@@ -16,7 +16,7 @@ const Ops* get_ops_av(int dtype, int g) {
       default: return nullptr;
     }
   } else if (dtype == F32) {
-    if (g == 0) g = 6;
+    if (g == 0) g = 3;
     switch (g) {
       case 1: return OpsImpl<ModelAV, float, 1>::get();
       case 101: return OpsImpl<ModelAV, float, 1, LAYOUT_PACKED>::get();  // symmetric-packed P

@@ -9,8 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-LANES = {"uniform_velocity": {"f64": [1, 3, 101, 201, 301], "f32": [1, 3, 101, 201, 301]}, "uniform_acceleration": {"f64": [1, 3, 101, 201, 301], "f32": [1, 3, 101, 201, 301]},
-         "angular_rates": {"f64": [3, 6, 201, 301], "f32": [2, 3, 6, 201, 301]}, "angular_velocities": {"f64": [3, 6, 201, 301], "f32": [1, 3, 6, 101, 201, 301]}}
+LANES = {"uniform_velocity": {"f64": [1, 3, 101, 103, 201, 301], "f32": [1, 3, 101, 103, 201, 301]},
+         "uniform_acceleration": {"f64": [1, 3, 101, 103, 201, 301], "f32": [1, 3, 101, 103, 201, 301]},
+         "angular_rates": {"f64": [3, 6, 103, 106, 201, 301], "f32": [2, 3, 6, 102, 103, 106, 201, 301]},
+         "angular_velocities": {"f64": [3, 6, 103, 106, 201, 301], "f32": [1, 3, 6, 101, 103, 106, 201, 301]}}
 
 
 def main():
