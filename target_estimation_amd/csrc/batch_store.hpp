@@ -102,9 +102,8 @@ class Batch {
     const unsigned char* has_base; long has_stride;     // optional masks
     double* delta_dev; double* pose_dev;                // query outputs [size] / [size][7] (overwritten every tick)
   };
-  // tick s of the spec on `st`, without touching the batch clock.  With query: followed by the own-time
-  // sphere query of every slot -- inside the step kernel for the separable layouts (one launch), as a
-  // second launch for the dense ones.
+  // tick s of the spec on `st`, without touching the batch clock.  With query: the own-time sphere
+  // query of every slot runs inside the step kernel (one launch).
   void enqueue_tick(hipStream_t st, long s, double dt, const SeqSpec& spec, bool query, const double* origin, double radius);
   void account_sequence(long n_ticks, double dt, bool all_measured);
   // identity of everything a recorded launch sequence refers to

@@ -24,7 +24,7 @@ struct StepParams {
   int n_ticks = 1;        // > 1: temporally fused launch (state stays in registers for n_ticks ticks)
   long tick_stride = 0;   // elements between the measurement blocks of consecutive ticks
   long has_stride = 0;
-  // fused own-time sphere query (separable layouts, dense single-tick launches): q_delta != null selects it
+  // fused own-time sphere query (dense single-tick launches): q_delta != null selects it
   double q_origin[3] = {0, 0, 0};
   double q_radius = 0;
   double* q_delta = nullptr;
@@ -34,7 +34,7 @@ struct StepParams {
 struct Ops {
   LayoutInfo L;
   int wpb;  // wavefronts per workgroup of the step kernel
-  bool fused_query;  // step() honours StepParams::q_delta (separable layouts)
+  bool fused_query;  // step() honours StepParams::q_delta
   void (*step)(const StepParams&, hipStream_t);
   void (*init)(const InitArgs&, hipStream_t);
   void (*get_state)(char* rec, const int* idx, long n, double* x, double* P, hipStream_t);

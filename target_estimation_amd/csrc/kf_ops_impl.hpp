@@ -24,8 +24,8 @@ struct OpsImpl {
     a.n_ticks = p.n_ticks; a.tick_stride = p.tick_stride; a.has_stride = p.has_stride;
     a.q_origin[0] = p.q_origin[0]; a.q_origin[1] = p.q_origin[1]; a.q_origin[2] = p.q_origin[2];
     a.q_radius = p.q_radius; a.q_delta = p.q_delta; a.q_pose = p.q_pose;
-    if (p.q_delta && (!C::SEP || p.idx || p.n_ticks > 1))
-      throw std::runtime_error("target_estimation_amd: the fused query needs a separable layout and a dense single-tick launch");
+    if (p.q_delta && (p.idx || p.n_ticks > 1))
+      throw std::runtime_error("target_estimation_amd: the fused query needs a dense single-tick launch");
     const long waves = (p.n + C::TPW - 1) / C::TPW;
     static const long small_grid = [] { const char* e = std::getenv("TE_SMALL_GRID_WAVES"); return e ? std::atol(e) : 1024L; }();
     // small (latency-bound) grids: one wavefront per workgroup spreads the waves over more CUs
@@ -50,6 +50,8 @@ struct OpsImpl {
         hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, false, true>), dim3(blocks), dim3(wpb_dense * 64), 0, s, a);
       else if (p.idx)
         hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, true>), dim3(blocks), dim3(wpb_dense * 64), 0, s, a);
+      else if (p.q_delta)
+        hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, false, false, true>), dim3(blocks), dim3(wpb_dense * 64), 0, s, a);
       else
         hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, false>), dim3(blocks), dim3(wpb_dense * 64), 0, s, a);
     }
@@ -95,7 +97,7 @@ struct OpsImpl {
   static const Ops* get() {
     static const Ops ops = {
         LayoutInfo{C::N, C::K, G, LAYOUT, C::TPW, C::LPT, C::RW, C::TILE_BYTES, C::TILE_PAYLOAD},
-        C::WPB, C::SEP, &step, &init, &get_state, &set_state, &move_record, &move_records, &outputs, &pack_meas, &intersect};
+        C::WPB, true, &step, &init, &get_state, &set_state, &move_record, &move_records, &outputs, &pack_meas, &intersect};
     return &ops;
   }
 };

@@ -23,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "kf_aux.hpp"
 #include "te_device_math.hpp"
 #include "te_layout.hpp"
 
@@ -101,10 +102,13 @@ __device__ __forceinline__ void store_record(char* tb, int lane, const T* rec) {
 
 template <typename T> __device__ __forceinline__ T sel3(int c, T a, T b, T d) { return c == 0 ? a : (c == 1 ? b : d); }
 
-template <class M, typename T, int G, int LAYOUT, bool INDEXED, bool FUSED = false>
+// QUERY: the own-time sphere query of the target runs after the store, on the posterior state (kf_aux.hpp,
+// sphere_query); with G > 1 the state is first collected from the G lanes through the wave's LDS scratch.
+template <class M, typename T, int G, int LAYOUT, bool INDEXED, bool FUSED = false, bool QUERY = false>
 __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kernel(const StepArgs<T> a) {
   using C = Cfg<M, T, G, LAYOUT>;
   constexpr bool PK = C::PK;
+  static_assert(!(QUERY && (INDEXED || FUSED)), "the fused query is for dense single-tick launches");
   static_assert(!C::SEP, "the separable layout has its own kernel (kf_step_sep.hpp)");
   constexpr int N = C::N, K = C::K, RPL = C::RPL, KPL = C::KPL, TPW = C::TPW, GS = C::GS;
   constexpr int kStepWaves = C::WPB, kStepThreads = C::WPB * 64;
@@ -600,6 +604,23 @@ __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kern
         if (a.has_meas != nullptr) a.nm_base[entry] += n_has;
       }
     }
+  }
+  if constexpr (QUERY) {
+    T xq[N];
+    if constexpr (G == 1) {
+#pragma unroll
+      for (int r = 0; r < N; ++r) xq[r] = X_(r);
+    } else {
+      // local row q of lane i is row (q / KPL) K + (q % KPL) G + i of the state
+      wave_lds_fence();
+#pragma unroll
+      for (int q = 0; q < RPL; ++q) EXA_((q / KPL) * K + (q % KPL) * G + i) = X_(q);
+      wave_lds_fence();
+#pragma unroll
+      for (int r = 0; r < N; ++r) xq[r] = EXA_(r);
+    }
+    if (valid && i == 0)
+      sphere_query<M, T>(xq, true, 0.0, 0.0, a.q_origin, a.q_radius, &a.q_delta[entry], a.q_pose ? &a.q_pose[entry * 7] : nullptr);
   }
 #undef P_
 #undef X_

@@ -112,8 +112,8 @@ class TargetManager {
   // n_ticks ticks of EVERY batch (specs in batch order), device-resident inputs: one step launch per
   // batch per tick, optionally followed by the own-time sphere query of every target.  The batches are
   // independent, so with use_graph != 0 each batch's chain of launches is its own branch of one hipGraph
-  // and the branches run concurrently; the query runs inside the step kernel for the separable layouts
-  // and as a second launch of the chain for the dense ones.  use_graph == 2 records without launching.  use_graph == 0 issues the same launches eagerly, batch after batch per tick.
+  // and the branches run concurrently; the query runs inside the step kernel (QUERY variants).
+  // use_graph == 2 records without launching.  use_graph == 0 issues the same launches eagerly, batch after batch per tick.
   void stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpec* specs, long n_specs, bool query,
                        const double* origin, double radius, int use_graph);
 

@@ -125,7 +125,7 @@ def test_convergence_gate_matches_oracle(models, name):
     mgr.close()
 
 
-@pytest.mark.parametrize("dtype,lanes", [("f64", 0), ("f32", 0), ("f64", 3), ("f32", 201)])
+@pytest.mark.parametrize("dtype,lanes", [("f64", 0), ("f32", 0), ("f64", 3), ("f32", 201), ("f64", 103), ("f32", 3)])
 @pytest.mark.parametrize("use_graph", [0, 1])
 def test_all_batches_sequence_equals_per_batch_calls(models, dtype, lanes, use_graph):
     """target_manager_step_sequence_all (the batches as concurrent branches of one hipGraph, with the per-tick
