@@ -78,7 +78,7 @@ MIXED = {
 }
 
 
-def run_mixed(te, torch, name, steps, warmup, dist=None, rank=0, world=1, stream_ticks=16, scale=1, launch_mode="graph"):
+def run_mixed(te, torch, name, steps, warmup, dist=None, rank=0, world=1, stream_ticks=64, scale=1, launch_mode="graph"):
     """Two batches in one manager, one step launch per batch per tick (+ one intersection launch per batch for
     cfg5); in graph mode the batches are concurrent branches of one hipGraph (target_manager_step_sequence_all).
     Returns cycles/s over both batches; algorithmic bytes are the sum of the batches' figures."""
@@ -184,7 +184,7 @@ def _model_params(model):
     return dict(Q=np.array(node["Q"]).reshape(n, n), R=np.array(node["R"]).reshape(m, m), P=np.array(node["P"]).reshape(n, n))
 
 
-def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None, rank=0, world=1, stream_ticks=32,
+def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None, rank=0, world=1, stream_ticks=64,
                  launch_mode="graph", gather=False):
     from target_estimation_amd.streams import make_stream
     desc, model, dtype, n_targets, seed = WORKLOADS[name]
@@ -451,8 +451,8 @@ def cpu_model():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=2048)   # whole 64-tick graph blocks
+    ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + sorted(MIXED))
     ap.add_argument("--lanes", type=int, default=0, help="lanes per target (0 = tuned default)")
     ap.add_argument("--targets", type=int, default=0, help="override targets per GPU")
@@ -461,6 +461,7 @@ def main():
                     help="extra workloads when --gpus > 1 (per-GPU sizes; every rank runs them in lockstep; NAME_strong = the workload's "
                          "targets split over the ranks)")
     ap.add_argument("--extra-steps", type=int, default=50)
+    ap.add_argument("--stream-ticks", type=int, default=0, help="ticks of synthetic measurements kept in HBM and replayed (= ticks per recorded graph); 0 = default")
     ap.add_argument("--scale", type=int, default=1, help="mixed workloads (cfg4/cfg5): multiply the per-GPU populations (8 = all 10^6 targets on one GPU)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--gather", action="store_true",
@@ -485,11 +486,13 @@ def main():
 
     if args.workload in MIXED:
         res = run_mixed(te, torch, args.workload, args.steps, args.warmup, dist, rank, world, scale=args.scale,
-                        launch_mode="graph" if args.launch_mode == "fused" else args.launch_mode)
+                        launch_mode="graph" if args.launch_mode == "fused" else args.launch_mode,
+                        **({"stream_ticks": args.stream_ticks} if args.stream_ticks else {}))
         mgr = None
     else:
         res = run_workload(te, torch, args.workload, args.steps, args.warmup, args.lanes, args.targets or None,
-                           dist, rank, world, launch_mode=args.launch_mode, gather=args.gather)
+                           dist, rank, world, launch_mode=args.launch_mode, gather=args.gather,
+                           **({"stream_ticks": args.stream_ticks} if args.stream_ticks else {}))
         mgr = res.pop("_mgr")
     out = {
         "metric": "KF predict+update cycles/sec over N targets",
@@ -561,7 +564,7 @@ def main():
         base, _, mult = name.partition("x")            # "cfg5x8": 8 x the per-GPU share = all 10^6 targets on this GPU
         if base in MIXED:
             sc = int(mult) if mult else 1
-            r = run_mixed(te, torch, base, max(args.extra_steps, 200) if sc == 1 else args.extra_steps, 20, dist, rank, world, scale=sc,
+            r = run_mixed(te, torch, base, 640 if sc == 1 else 128, 64, dist, rank, world, scale=sc,
                           launch_mode="graph" if args.launch_mode == "fused" else args.launch_mode)
             r["name"] = name
             if sc > 1:
