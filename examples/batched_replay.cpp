@@ -20,7 +20,7 @@ int main(int argc, char** argv) {
   const char* file = argc > 1 ? argv[1] : "models/model_uniform_velocity_params.yaml";
   const long n = argc > 2 ? std::atol(argv[2]) : 10000;
   const long steps = argc > 3 ? std::atol(argv[3]) : 2000;
-  const int ticks = 32;                      // block of measurements kept in HBM and replayed
+  const int ticks = 64;                      // block of measurements kept in HBM and replayed
   const double dt = 0.004;
 
   target_manager_c* m = target_manager_new(file);          // fp64, automatic layout
@@ -53,7 +53,7 @@ int main(int argc, char** argv) {
   hipStream_t stream;
   HIP_OK(hipStreamCreate(&stream));
   target_manager_set_stream(m, stream);
-  // record the 32-launch graph once, warm up, then time whole blocks
+  // record the 64-launch graph once, warm up, then time whole blocks
   if (target_batch_step_sequence(b, ticks, dt, d_meas, 7 * n, n, nullptr, 0, 2) != 0) return 5;
   for (int w = 0; w < 4; ++w) target_batch_step_sequence(b, ticks, dt, d_meas, 7 * n, n, nullptr, 0, 1);
   hipEvent_t e0, e1;

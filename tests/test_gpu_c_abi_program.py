@@ -44,4 +44,4 @@ def test_cpp_example_of_the_batch_api(tmp_path):
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "5000 targets, 256 ticks" in out.stdout and "predict+update cycles/s" in out.stdout
-    assert "384 measurements" in out.stdout          # 256 timed + 4 warm-up blocks of 32 ticks
+    assert "512 measurements" in out.stdout          # 256 timed + 4 warm-up blocks of 64 ticks
