@@ -34,6 +34,10 @@ TUNED_LANES = {"cfg2_full": 3, "uv1m_full": 1, "ua1m_full": 1, "ar1m_full": 6, "
                "ar1m_packed": 103, "av1m_packed": 101,   # what coupled but symmetric Q, R, P0 get automatically
                "uv1m_s201": 201, "ua1m_s201": 201, "av1m_s201": 201, "ar1m_s201": 201}
 
+GRAPH_TICKS = 64   # ticks per recorded hipGraph (best block length for configs[1]: 16/32/64/128 -> 2.65/2.38/2.26/2.83 us per tick)
+# measurement ring lengths (ticks) of the *_stream workloads: the ring is >= 1 GiB, far beyond L2 (32 MB) + Infinity Cache (256 MB)
+RINGS = {"cfg2_stream": 2048, "cfg3_stream": 512}
+
 # stream variants: availability < 1 = per-(target, tick) measurement mask (predict-only otherwise); rpy_noise = orientation noise
 VARIANTS = {"ar1m_a90": dict(availability=0.9, rpy_noise=0.1), "av1m_a90": dict(availability=0.9, rpy_noise=0.1)}
 
@@ -41,6 +45,9 @@ WORKLOADS = {
     # name: (description, model, dtype, targets per GPU, seed)
     "cfg2": ("10000 targets, uniform-velocity model, fp64 (BASELINE.json configs[1])", "uniform_velocity", "f64", 10_000, 20240002),
     "cfg3": ("100000 targets, uniform-acceleration model, fp32 (configs[2])", "uniform_acceleration", "f32", 100_000, 20240003),
+    "cfg2_stream": ("configs[1] with a measurement ring of 2048 ticks (1.1 GB): every tick's measurements come from HBM, not from L2",
+                    "uniform_velocity", "f64", 10_000, 20240002),
+    "cfg3_stream": ("configs[2] with a measurement ring of 512 ticks (1.4 GB)", "uniform_acceleration", "f32", 100_000, 20240003),
     "cfg4ar": ("angular-rates half of configs[3], 62500 targets per GPU, fp32", "angular_rates", "f32", 62_500, 20240004),
     "cfg4av": ("angular-velocities half of configs[3], 62500 targets per GPU, fp32", "angular_velocities", "f32", 62_500, 20240004),
     "uv1m": ("1000000 targets, uniform-velocity model, fp64", "uniform_velocity", "f64", 1_000_000, 20240012),
@@ -197,7 +204,14 @@ def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None,
     mgr.set_stream(torch.cuda.current_stream().cuda_stream)
     mtype = te.MODEL_TYPES[model]
     dt = 1.0 / 250.0
-    ticks = min(stream_ticks, steps + warmup)
+    # The synthetic measurements live in HBM as a ring of `ticks` ticks that the run cycles through; in graph mode
+    # every GRAPH_TICKS-tick block of the ring is one recorded hipGraph.  Default ring = one block; RINGS gives
+    # the *_stream workloads a ring far larger than L2 + Infinity Cache, so that every tick's measurements come
+    # from HBM itself.
+    ring_want = RINGS.get(name, stream_ticks)
+    ticks = min(ring_want, steps + warmup)
+    if ticks > GRAPH_TICKS:
+        ticks -= ticks % GRAPH_TICKS
     st = make_stream(mtype, n_targets, ticks, dt, seed + 1000 * rank, **VARIANTS.get(name, {}))
     has = st["has_meas"]    # [ticks, N] uint8 or None
     import numpy as np
@@ -205,7 +219,9 @@ def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None,
     mgr.init_batch(ids, dt, 0.0, st["p0"].cpu().numpy())
     b = mgr.batches()[0]
     meas = st["meas"].to(b.torch_dtype()).contiguous()   # [ticks, 7, N] in the batch precision
+    del st
     torch.cuda.synchronize()
+    gb = min(GRAPH_TICKS, ticks)
 
     # One launch of the step kernel per tick in every mode.  "python": one C-ABI call per tick;
     # "sequence": the launches of a block of ticks are enqueued by one C call
@@ -220,19 +236,20 @@ def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None,
             return
         while count > 0:
             off = done[0] % ticks
-            blk = min(count, ticks - off)
-            # only whole blocks are replayed from the recorded graph (one graph, recorded during
-            # warm-up); partial blocks are enqueued launch by launch
+            blk = min(count, gb - off % gb)
+            # only whole blocks are replayed from the recorded graphs (recorded before the timed region);
+            # partial blocks are enqueued launch by launch
             if launch_mode == "fused":   # temporally fused: the whole block in ONE launch ("effective" metric)
                 b.step_fused(dt, meas[off:off + blk], None if has is None else has[off:off + blk])
             else:
                 b.step_sequence(dt, meas[off:off + blk], None if has is None else has[off:off + blk],
-                                use_graph=(launch_mode == "graph" and off == 0 and blk == ticks))
+                                use_graph=(launch_mode == "graph" and off % gb == 0 and blk == gb))
             done[0] += blk
             count -= blk
 
     if launch_mode == "graph":
-        b.step_sequence(dt, meas, has, use_graph=2)   # record the block's graph now (set-up; launches nothing)
+        for off in range(0, ticks - gb + 1, gb):   # record every block's graph now (set-up; launches nothing)
+            b.step_sequence(dt, meas[off:off + gb], None if has is None else has[off:off + gb], use_graph=2)
     run_ticks(warmup)
     torch.cuda.synchronize()
     if dist is not None:
@@ -280,7 +297,7 @@ def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None,
         res["gather_pose_ms"] = (time.perf_counter() - tg) * 1e3
         if rank == 0:
             assert full.shape == (n_targets * world, 7) and bool(torch.isfinite(full).all())
-    res["_mgr"] = (mgr, b, st, ids, dt)
+    res["_mgr"] = (mgr, b, None, ids, dt)
     return res
 
 
@@ -456,7 +473,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + sorted(MIXED))
     ap.add_argument("--lanes", type=int, default=0, help="lanes per target (0 = tuned default)")
     ap.add_argument("--targets", type=int, default=0, help="override targets per GPU")
-    ap.add_argument("--extra", default="cfg3,cfg4,cfg5,cfg4x8,cfg5x8,uv1m,ua1m,av1m,ar1m,ar1m_a90,av1m_a90,ar1m_s201,av1m_s201,cfg2_full,uv1m_full,uv1m_packed,ar1m_full,ar1m_packed", help="comma list of extra workloads reported under 'extra' (N=1 only; '' = none)")
+    ap.add_argument("--extra", default="cfg2_stream,cfg3,cfg3_stream,cfg4,cfg5,cfg4x8,cfg5x8,uv1m,ua1m,av1m,ar1m,ar1m_a90,av1m_a90,ar1m_s201,av1m_s201,cfg2_full,uv1m_full,uv1m_packed,ar1m_full,ar1m_packed", help="comma list of extra workloads reported under 'extra' (N=1 only; '' = none)")
     ap.add_argument("--extra-multi", default="uv1m,ua1m,av1m,ar1m,cfg4,cfg5,uv1m_strong,ar1m_strong",
                     help="extra workloads when --gpus > 1 (per-GPU sizes; every rank runs them in lockstep; NAME_strong = the workload's "
                          "targets split over the ranks)")
@@ -579,7 +596,7 @@ def main():
             r["desc"] += " -- strong scaling: %d targets in total, %d per GPU" % (per_rank * world, per_rank)
         else:
             small = WORKLOADS[name][3] <= 200000
-            r = run_workload(te, torch, name, 1920 if small else args.extra_steps, 64 if small else 10, 0,
+            r = run_workload(te, torch, name, (4096 if name in RINGS else 1920) if small else args.extra_steps, 64 if small else 10, 0,
                              dist=dist, rank=rank, world=world, launch_mode=args.launch_mode)
             r.pop("_mgr")
         extras.append({k: r[k] for k in ("name", "desc", "dtype", "targets_per_gpu", "lanes_per_target", "layout", "cycles_per_s",

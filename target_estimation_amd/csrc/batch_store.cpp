@@ -252,7 +252,7 @@ void Batch::step_sequence(long n_ticks, double dt, const void* meas_base, long t
       if (g.n_ticks == n_ticks && g.tick_stride == tick_stride && g.ld == ld && g.has_stride == has_stride && g.n == n_ &&
           g.dt == dt && g.meas_base == meas_base && g.has_base == has_base && g.rec == d_rec_) hit = &g;
     if (!hit) {
-      if (graphs_.size() >= 8) drop_graphs();
+      if (graphs_.size() >= 64) drop_graphs();   // e.g. a ring of 4096 ticks replayed in 64-tick blocks
       if (!cap_stream_) TE_HIP_CHECK(hipStreamCreateWithFlags(&cap_stream_, hipStreamNonBlocking));
       GraphEntry e{n_ticks, tick_stride, ld, has_stride, n_, dt, meas_base, has_base, d_rec_, nullptr, nullptr};
       TE_HIP_CHECK(hipStreamBeginCapture(cap_stream_, hipStreamCaptureModeThreadLocal));

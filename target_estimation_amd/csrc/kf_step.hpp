@@ -228,7 +228,25 @@ __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kern
   for (int tick = 0; tick < n_ticks; ++tick) {
   const T* meas_t = a.meas ? a.meas + (long)tick * a.tick_stride : nullptr;
   const unsigned char* has_t = a.has_meas ? a.has_meas + (long)tick * a.has_stride : nullptr;
-  const bool has = valid && meas_t != nullptr && (has_t == nullptr || has_t[entry] != 0);
+  // Every measurement word this lane needs is requested up front, right behind the record loads and
+  // regardless of the mask (one round trip instead of one per use; see kf_step_sep.hpp).
+  T ymeas_own[KPL], qmeas[4] = {0, 0, 0, 1};
+#pragma unroll
+  for (int qq = 0; qq < KPL; ++qq) ymeas_own[qq] = 0;
+  unsigned char hmask = 1;
+  if (valid && meas_t != nullptr) {
+#pragma unroll
+    for (int qq = 0; qq < KPL; ++qq) {
+      const int r = i + G * qq;
+      if (!M::ANGULAR || r < 3) ymeas_own[qq] = meas_t[(long)r * a.meas_ld + entry];
+    }
+    if constexpr (M::ANGULAR) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) qmeas[c] = meas_t[(long)(3 + c) * a.meas_ld + entry];
+    }
+    if (has_t != nullptr) hmask = has_t[entry];
+  }
+  const bool has = valid && meas_t != nullptr && hmask != 0;
   n_has += has ? 1 : 0;
 
   // ------------------------------------------------------------------ measurement conversion
@@ -237,10 +255,10 @@ __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kern
   if constexpr (M::ANGULAR) {
     if (has) {
       T q[4];
-      q[0] = meas_t[3 * a.meas_ld + entry];
-      q[1] = meas_t[4 * a.meas_ld + entry];
-      q[2] = meas_t[5 * a.meas_ld + entry];
-      q[3] = meas_t[6 * a.meas_ld + entry];
+      q[0] = qmeas[0];
+      q[1] = qmeas[1];
+      q[2] = qmeas[2];
+      q[3] = qmeas[3];
       quat_normalize(q);
       quat_to_rpy(q, mrpy);
     }
@@ -484,7 +502,7 @@ __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kern
         const int r = i + G * qq;
         T y;
         if (!M::ANGULAR || r < 3) {
-          y = meas_t[(long)r * a.meas_ld + entry];
+          y = ymeas_own[qq];
         } else {
           const int cc = r - 3;
           const int us = cc / G;

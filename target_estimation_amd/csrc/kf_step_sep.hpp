@@ -121,17 +121,30 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
   for (int tick = 0; tick < n_ticks; ++tick) {
   const T* meas_t = a.meas ? a.meas + (long)tick * a.tick_stride : nullptr;
   const unsigned char* has_t = a.has_meas ? a.has_meas + (long)tick * a.has_stride : nullptr;
-  const bool has = valid && meas_t != nullptr && (has_t == nullptr || has_t[entry] != 0);
+  // Every measurement word of the tick is requested up front, right behind the record loads and regardless
+  // of the mask: with a cache-resident state they are the only operands that come from HBM itself, and one
+  // round trip for all of them replaces one per axis.
+  constexpr int MW = M::ANGULAR ? 7 : 3;
+  T ymeas[MW];
+#pragma unroll
+  for (int c = 0; c < MW; ++c) ymeas[c] = 0;
+  unsigned char hmask = 1;
+  if (valid && meas_t != nullptr) {
+#pragma unroll
+    for (int c = 0; c < MW; ++c) ymeas[c] = meas_t[(long)c * a.meas_ld + entry];
+    if (has_t != nullptr) hmask = has_t[entry];
+  }
+  const bool has = valid && meas_t != nullptr && hmask != 0;
   n_has += has ? 1 : 0;
 
   T mrpy[3] = {0, 0, 0};
   if constexpr (M::ANGULAR) {
     if (has) {
       T q[4];
-      q[0] = meas_t[3 * a.meas_ld + entry];
-      q[1] = meas_t[4 * a.meas_ld + entry];
-      q[2] = meas_t[5 * a.meas_ld + entry];
-      q[3] = meas_t[6 * a.meas_ld + entry];
+      q[0] = ymeas[3];
+      q[1] = ymeas[4];
+      q[2] = ymeas[5];
+      q[3] = ymeas[6];
       quat_normalize(q);
       quat_to_rpy(q, mrpy);
     }
@@ -159,7 +172,7 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
     T y = 0;
     if (has) {
       if (!M::ANGULAR || i < 3) {
-        y = meas_t[(long)i * a.meas_ld + entry];
+        y = ymeas[i];
       } else {
         y = unwrap_angle(UWW_(i - 3), mrpy[i - 3]);   // angular_rates.cpp:85-88
         UWW_(i - 3) = y;
