@@ -283,7 +283,8 @@ def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None,
         device_ms_per_launch=launch_s * 1e3,
         algorithmic_bytes_per_cycle=b.algorithmic_bytes, algorithmic_bytes_per_launch=alg_bytes,
         achieved_gbs=alg_bytes / launch_s / 1e9,
-        resident_bytes_per_target=b.resident_bytes_per_target, launch_mode=launch_mode)
+        resident_bytes_per_target=b.resident_bytes_per_target, launch_mode=launch_mode,
+        measurement_ring_ticks=ticks, measurement_ring_bytes=int(meas.numel() * meas.element_size()))
     if gather and dist is not None:
         from target_estimation_amd import dist as td
         pose, _, _ = b.get_est(twist=False, acc=False)
@@ -520,6 +521,9 @@ def main():
         "config": {"workload": res["desc"], "name": res["name"], "motion_model": res["model"],
                    "targets_per_gpu": res["targets_per_gpu"], "targets_total": res["targets_per_gpu"] * world,
                    "lanes_per_target": res["lanes_per_target"], "P_layout": res["layout"], "dt": 0.004, "launch_mode": res["launch_mode"],
+                   "measurements": ("synthetic, resident in HBM as a ring of %d ticks (%d MB) that the run cycles through; 'extra' has the same "
+                                    "workload with a ring beyond L2 + Infinity Cache (cfg2_stream)" % (res["measurement_ring_ticks"], res["measurement_ring_bytes"] // 1000000))
+                   if "measurement_ring_ticks" in res else "synthetic, resident in HBM",
                    "sharding": "contiguous id ranges per rank, no data-path collective"} |
                   ({"gather_pose_ms": res["gather_pose_ms"]} if "gather_pose_ms" in res else {}),
         "roofline": {"bound": "hbm", "achieved": res["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
