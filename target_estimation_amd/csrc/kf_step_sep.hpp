@@ -116,6 +116,38 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
   const T dt = (T)dtd;
   const T* Qm = a.qr;
   const T* Rm = a.qr + N * N;
+  // the [p v (a)] chains.  Linear models: K of them, rows {i, i+K, i+2K}.  EKF: x, y, z with rows
+  // {i, i+6} (position, velocity), plus the 6-state attitude group (rows 3..5, 9..11).
+  constexpr int NLIN = M::EKF ? 3 : K;
+  constexpr int LB = M::EKF ? 2 : NB;         // states per chain
+  constexpr int STRIDE = M::EKF ? 6 : K;      // row distance between the states of a chain
+  constexpr int GRA[6] = {3, 4, 5, 9, 10, 11};
+  // Q and R of every chain are uniform (scalar loads): when they fit the scalar registers they are requested
+  // once, here, behind the record loads, instead of chain by chain with a wait each (a serial chain of
+  // scalar-cache round trips that a small, latency-bound batch feels directly).
+  constexpr int QR_NEED = NLIN * LB * LB + NLIN + (M::EKF ? 36 + 9 : 0);
+  constexpr bool HOIST_QR = QR_NEED * (int)sizeof(T) <= 256;
+  T Qlin[HOIST_QR ? NLIN : 1][LB][LB], Rlin[HOIST_QR ? NLIN : 1], Qatt[HOIST_QR && M::EKF ? 6 : 1][6], Ratt[HOIST_QR && M::EKF ? 3 : 1][3];
+  if constexpr (HOIST_QR) {
+#pragma unroll
+    for (int i = 0; i < NLIN; ++i) {
+#pragma unroll
+      for (int b = 0; b < LB; ++b)
+#pragma unroll
+        for (int c = 0; c < LB; ++c) Qlin[i][b][c] = Qm[(i + STRIDE * b) * N + (i + STRIDE * c)];
+      Rlin[i] = Rm[i * K + i];
+    }
+    if constexpr (M::EKF) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) Qatt[r][c] = Qm[GRA[r] * N + GRA[c]];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Ratt[r][c] = Rm[(3 + r) * K + (3 + c)];
+    }
+  }
   int n_has = 0;
   const int n_ticks = FUSED ? a.n_ticks : 1;
   for (int tick = 0; tick < n_ticks; ++tick) {
@@ -136,6 +168,30 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
   }
   const bool has = valid && meas_t != nullptr && hmask != 0;
   n_has += has ? 1 : 0;
+  if constexpr (HOIST_QR) {
+    // pin the hoisted Q / R values into scalar registers here, i.e. wait for their loads now, while the record
+    // and measurement loads are still in flight (otherwise the compiler sinks them back next to their uses)
+    if (tick == 0) {
+#pragma unroll
+      for (int i = 0; i < NLIN; ++i) {
+#pragma unroll
+        for (int b = 0; b < LB; ++b)
+#pragma unroll
+          for (int c = 0; c < LB; ++c) asm volatile("" : "+s"(Qlin[i][b][c]));
+        asm volatile("" : "+s"(Rlin[i]));
+      }
+      if constexpr (M::EKF) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c = 0; c < 6; ++c) asm volatile("" : "+s"(Qatt[r][c]));
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) asm volatile("" : "+s"(Ratt[r][c]));
+      }
+    }
+  }
 
   T mrpy[3] = {0, 0, 0};
   if constexpr (M::ANGULAR) {
@@ -152,11 +208,7 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
 #define XW_(r) mem[C::X_OFF + (r)]
 #define UWW_(s) mem[C::UW_OFF + (s)]
 
-  // ---- the [p v (a)] chains.  Linear models: K of them, rows {i, i+K, i+2K}.  EKF: x, y, z with
-  // rows {i, i+6} (position, velocity).
-  constexpr int NLIN = M::EKF ? 3 : K;
-  constexpr int LB = M::EKF ? 2 : NB;         // states per chain
-  constexpr int STRIDE = M::EKF ? 6 : K;      // row distance between the states of a chain
+  // ---- the [p v (a)] chains
 #pragma unroll
   for (int i = 0; i < NLIN; ++i) {
     T xs[LB], Pb[LB][LB], Qb[LB][LB];
@@ -166,7 +218,8 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
 #pragma unroll
       for (int c = 0; c < LB; ++c) {
         Pb[b][c] = mem[C::PWORD.v[i + STRIDE * b][i + STRIDE * c]];
-        Qb[b][c] = Qm[(i + STRIDE * b) * N + (i + STRIDE * c)];
+        if constexpr (HOIST_QR) Qb[b][c] = Qlin[i][b][c];
+        else Qb[b][c] = Qm[(i + STRIDE * b) * N + (i + STRIDE * c)];
       }
     }
     T y = 0;
@@ -178,7 +231,10 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
         UWW_(i - 3) = y;
       }
     }
-    sep_linear_axis<LB, T>(xs, Pb, Qb, Rm[i * K + i], dt, has, y);
+    T r_meas;
+    if constexpr (HOIST_QR) r_meas = Rlin[i];
+    else r_meas = Rm[i * K + i];
+    sep_linear_axis<LB, T>(xs, Pb, Qb, r_meas, dt, has, y);
 #pragma unroll
     for (int b = 0; b < LB; ++b) {
       XW_(i + STRIDE * b) = xs[b];
@@ -266,14 +322,24 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
         nw[cc] = v;
       }
 #pragma unroll
-      for (int c = 0; c < 6; ++c) Pr[r][c] = (c < 3 ? nw[c < 3 ? c : 0] : Pr[r][c]) + Qm[GR[r] * N + GR[c]];
+      for (int c = 0; c < 6; ++c) {
+        T qrc;
+        if constexpr (HOIST_QR) qrc = Qatt[r][c];
+        else qrc = Qm[GR[r] * N + GR[c]];
+        Pr[r][c] = (c < 3 ? nw[c < 3 ? c : 0] : Pr[r][c]) + qrc;
+      }
     }
     if (has) {
       T S[3][3];
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) S[r][c] = Pr[r][c] + Rm[(3 + r) * K + (3 + c)];
+        for (int c = 0; c < 3; ++c) {
+          T rrc;
+          if constexpr (HOIST_QR) rrc = Ratt[r][c];
+          else rrc = Rm[(3 + r) * K + (3 + c)];
+          S[r][c] = Pr[r][c] + rrc;
+        }
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
         const T inv = (T)1 / S[p][p];
