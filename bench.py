@@ -34,7 +34,8 @@ TUNED_LANES = {"cfg2_full": 3, "uv1m_full": 1, "ua1m_full": 1, "ar1m_full": 6, "
                "ar1m_packed": 103, "av1m_packed": 101,   # what coupled but symmetric Q, R, P0 get automatically
                "uv1m_s201": 201, "ua1m_s201": 201, "av1m_s201": 201, "ar1m_s201": 201}
 
-GRAPH_TICKS = 64   # ticks per recorded hipGraph (best block length for configs[1]: 16/32/64/128 -> 2.65/2.38/2.26/2.83 us per tick)
+GRAPH_PASSES = 4   # passes over a one-block measurement ring per recorded graph (small batches only)
+GRAPH_TICKS = 64   # ticks per block of the measurement ring = per recorded hipGraph (best block length for configs[1]: 16/32/64/128 -> 2.65/2.38/2.26/2.83 us per tick)
 # measurement ring lengths (ticks) of the *_stream workloads: the ring is >= 1 GiB, far beyond L2 (32 MB) + Infinity Cache (256 MB)
 RINGS = {"cfg2_stream": 2048, "cfg3_stream": 512}
 
@@ -133,13 +134,20 @@ def run_mixed(te, torch, name, steps, warmup, dist=None, rank=0, world=1, stream
         s, end = first, first + count
         while s < end:
             o = s % ticks
+            if passes > 1 and o == 0 and end - s >= ticks * passes:   # several passes over the ring in one graph
+                mgr.step_sequence_all(dt, meas, query=query, use_graph=1, n_ticks=ticks * passes)
+                s += ticks * passes
+                continue
             nblk = min(ticks - o, end - s)
             whole = launch_mode == "graph" and o == 0 and nblk == ticks
             mgr.step_sequence_all(dt, [m[o:o + nblk] for m in meas], query=query, use_graph=1 if whole else 0)
             s += nblk
 
+    passes = GRAPH_PASSES if (launch_mode == "graph" and ticks == GRAPH_TICKS and scale == 1) else 1
     if launch_mode == "graph":
         mgr.step_sequence_all(dt, meas, query=query, use_graph=2)    # record before the timed region
+        if passes > 1:
+            mgr.step_sequence_all(dt, meas, query=query, use_graph=2, n_ticks=ticks * passes)
     run(0, warmup)
     torch.cuda.synchronize()
     if dist is not None:
@@ -222,6 +230,9 @@ def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None,
     del st
     torch.cuda.synchronize()
     gb = min(GRAPH_TICKS, ticks)
+    # A one-block ring of a small (launch-bound) batch is replayed GRAPH_PASSES times per recorded graph
+    # (target_batch_step_sequence_ring): every graph launch costs ~8 us, a noticeable share of 64 x 2 us.
+    passes = GRAPH_PASSES if (launch_mode == "graph" and ticks == gb == GRAPH_TICKS and n_targets <= 200000) else 1
 
     # One launch of the step kernel per tick in every mode.  "python": one C-ABI call per tick;
     # "sequence": the launches of a block of ticks are enqueued by one C call
@@ -236,6 +247,11 @@ def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None,
             return
         while count > 0:
             off = done[0] % ticks
+            if passes > 1 and off == 0 and count >= gb * passes:      # several passes over the ring in one graph
+                b.step_sequence(dt, meas, has, use_graph=True, n_ticks=gb * passes)
+                done[0] += gb * passes
+                count -= gb * passes
+                continue
             blk = min(count, gb - off % gb)
             # only whole blocks are replayed from the recorded graphs (recorded before the timed region);
             # partial blocks are enqueued launch by launch
@@ -250,6 +266,8 @@ def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None,
     if launch_mode == "graph":
         for off in range(0, ticks - gb + 1, gb):   # record every block's graph now (set-up; launches nothing)
             b.step_sequence(dt, meas[off:off + gb], None if has is None else has[off:off + gb], use_graph=2)
+        if passes > 1:
+            b.step_sequence(dt, meas, has, use_graph=2, n_ticks=gb * passes)
     run_ticks(warmup)
     torch.cuda.synchronize()
     if dist is not None:
@@ -322,7 +340,7 @@ def host_threads(omp_max):
     return max(1, n)
 
 
-def launch_floor(torch, nbytes, reps=32, rounds=40):
+def launch_floor(torch, nbytes, reps=256, rounds=8):
     """Period of a DEPENDENT launch on this box: a trivial in-place read-modify-write of `nbytes` (the tick's
     working set), `reps` launches recorded in a graph and replayed.  No tick over that working set can be
     shorter with one launch per tick; it bounds the roofline fraction of launch-bound (small) batches."""

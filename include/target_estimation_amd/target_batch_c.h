@@ -170,6 +170,10 @@ int target_batch_step(target_batch_c* b, double dt, const void* meas_dev, long l
  * use_graph == 2 records the graph and launches nothing (set-up before a timed region). */
 int target_batch_step_sequence(target_batch_c* b, long n_ticks, double dt, const void* meas_dev, long tick_stride, long ld,
                                const unsigned char* has_meas_dev, long has_stride, int use_graph);
+/* The same with the measurements (and masks) held as a RING of ring_ticks ticks: tick s reads ring entry
+ * s % ring_ticks, so one recorded graph may hold several passes over the ring (fewer graph launches). */
+int target_batch_step_sequence_ring(target_batch_c* b, long n_ticks, double dt, const void* meas_dev, long tick_stride, long ld,
+                                    const unsigned char* has_meas_dev, long has_stride, long ring_ticks, int use_graph);
 /* The same n_ticks ticks in ONE launch: each target's state stays in registers across the ticks and
  * only the measurements are read per tick (temporal fusion; identical results).  For replaying
  * recorded streams; its throughput is an "effective" figure, not comparable with one launch per tick. */
@@ -187,6 +191,7 @@ typedef struct target_batch_sequence_c {
   const void* meas_dev; long tick_stride; long ld;
   const unsigned char* has_meas_dev; long has_stride;
   double* delta_dev; double* pose_dev;
+  long ring_ticks;   /* > 0: meas_dev / has_meas_dev hold a ring of that many ticks, tick s reads entry s % ring_ticks; 0: linear */
 } target_batch_sequence_c;
 int target_manager_step_sequence_all(target_manager_c* m, long n_ticks, double dt, const target_batch_sequence_c* per_batch,
                                      long n_batches, int query, const double* origin, double radius, int use_graph);

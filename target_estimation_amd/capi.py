@@ -18,7 +18,7 @@ class BatchSequence(C.Structure):
     """target_batch_sequence_c of target_batch_c.h"""
     _fields_ = [("meas_dev", C.c_void_p), ("tick_stride", C.c_long), ("ld", C.c_long),
                 ("has_meas_dev", C.c_void_p), ("has_stride", C.c_long),
-                ("delta_dev", C.c_void_p), ("pose_dev", C.c_void_p)]
+                ("delta_dev", C.c_void_p), ("pose_dev", C.c_void_p), ("ring_ticks", C.c_long)]
 
 
 SIGNATURES = {
@@ -91,6 +91,7 @@ SIGNATURES = {
     "target_batch_slot_ids": (C.c_long, [C.c_void_p, c_uint_p, C.c_long]),
     "target_batch_step": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_long, C.c_void_p]),
     "target_batch_step_sequence": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_int]),
+    "target_batch_step_sequence_ring": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_int]),
     "target_manager_step_sequence_all": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_long, C.c_int, c_double_p, C.c_double, C.c_int]),
     "target_batch_step_fused": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long]),
     "target_batch_get_est_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double]),

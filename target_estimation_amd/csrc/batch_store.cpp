@@ -230,11 +230,12 @@ void Batch::drop_graphs() {
 }
 
 void Batch::step_sequence(long n_ticks, double dt, const void* meas_base, long tick_stride, long ld,
-                          const unsigned char* has_base, long has_stride, int use_graph) {
+                          const unsigned char* has_base, long has_stride, int use_graph, long ring_ticks) {
   touch();
   if (n_ == 0 || n_ticks <= 0) return;
   const size_t es = elem_size();
-  auto params = [&](long s) {
+  auto params = [&](long s0) {
+    const long s = ring_ticks > 0 ? s0 % ring_ticks : s0;   // the measurements form a ring of ring_ticks ticks
     StepParams p;
     p.rec = d_rec_; p.qr = d_qr_; p.n = n_; p.idx = nullptr;
     p.meas = meas_base ? static_cast<const char*>(meas_base) + (size_t)(s * tick_stride) * es : nullptr;
@@ -250,11 +251,11 @@ void Batch::step_sequence(long n_ticks, double dt, const void* meas_base, long t
     GraphEntry* hit = nullptr;
     for (auto& g : graphs_)
       if (g.n_ticks == n_ticks && g.tick_stride == tick_stride && g.ld == ld && g.has_stride == has_stride && g.n == n_ &&
-          g.dt == dt && g.meas_base == meas_base && g.has_base == has_base && g.rec == d_rec_) hit = &g;
+          g.dt == dt && g.meas_base == meas_base && g.has_base == has_base && g.rec == d_rec_ && g.ring_ticks == ring_ticks) hit = &g;
     if (!hit) {
       if (graphs_.size() >= 64) drop_graphs();   // e.g. a ring of 4096 ticks replayed in 64-tick blocks
       if (!cap_stream_) TE_HIP_CHECK(hipStreamCreateWithFlags(&cap_stream_, hipStreamNonBlocking));
-      GraphEntry e{n_ticks, tick_stride, ld, has_stride, n_, dt, meas_base, has_base, d_rec_, nullptr, nullptr};
+      GraphEntry e{n_ticks, tick_stride, ld, has_stride, n_, dt, meas_base, has_base, d_rec_, nullptr, nullptr, ring_ticks};
       TE_HIP_CHECK(hipStreamBeginCapture(cap_stream_, hipStreamCaptureModeThreadLocal));
       for (long s = 0; s < n_ticks; ++s) ops_->step(params(s), cap_stream_);
       TE_HIP_CHECK(hipStreamEndCapture(cap_stream_, &e.graph));
@@ -271,6 +272,7 @@ void Batch::step_sequence(long n_ticks, double dt, const void* meas_base, long t
 
 void Batch::enqueue_tick(hipStream_t st, long s, double dt, const SeqSpec& q, bool query, const double* origin, double radius) {
   if (n_ == 0) return;
+  if (q.ring_ticks > 0) s %= q.ring_ticks;
   const size_t es = elem_size();
   StepParams p;
   p.rec = d_rec_; p.qr = d_qr_; p.n = n_; p.idx = nullptr;

@@ -55,7 +55,7 @@ class Batch {
   // enqueued from C++ (use_graph 1: recorded once into a hipGraph and replayed, which removes the
   // per-launch host cost when a recorded stream is replayed; 2: record only, launch nothing).
   void step_sequence(long n_ticks, double dt, const void* meas_base, long tick_stride, long ld,
-                     const unsigned char* has_base, long has_stride, int use_graph);
+                     const unsigned char* has_base, long has_stride, int use_graph, long ring_ticks = 0);
   // n_ticks ticks in ONE launch: every target's state stays in registers across the ticks and only
   // the measurements are read per tick.  Same results as n_ticks single ticks; a different
   // ("effective", temporally fused) cost model -- for replaying recorded streams.
@@ -101,6 +101,7 @@ class Batch {
     const void* meas_base; long tick_stride; long ld;   // tick s reads meas_base + s*tick_stride elements, SoA [7][ld]
     const unsigned char* has_base; long has_stride;     // optional masks
     double* delta_dev; double* pose_dev;                // query outputs [size] / [size][7] (overwritten every tick)
+    long ring_ticks;                                    // > 0: the measurements are a ring, tick s reads entry s % ring_ticks
   };
   // tick s of the spec on `st`, without touching the batch clock.  With query: the own-time sphere
   // query of every slot runs inside the step kernel (one launch).
@@ -167,6 +168,7 @@ class Batch {
     char* rec;
     hipGraphExec_t exec;
     hipGraph_t graph;
+    long ring_ticks;
   };
   std::vector<GraphEntry> graphs_;
   hipStream_t cap_stream_ = nullptr;

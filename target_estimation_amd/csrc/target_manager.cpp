@@ -700,7 +700,7 @@ void TargetManager::stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpe
   } else {
     auto same_spec = [](const Batch::SeqSpec& x, const Batch::SeqSpec& y) {
       return x.meas_base == y.meas_base && x.tick_stride == y.tick_stride && x.ld == y.ld && x.has_base == y.has_base &&
-             x.has_stride == y.has_stride && x.delta_dev == y.delta_dev && x.pose_dev == y.pose_dev;
+             x.has_stride == y.has_stride && x.delta_dev == y.delta_dev && x.pose_dev == y.pose_dev && x.ring_ticks == y.ring_ticks;
     };
     auto same_id = [](const Batch::DevIdentity& x, const Batch::DevIdentity& y) {
       return x.rec == y.rec && x.qr == y.qr && x.tbase == y.tbase && x.nmbase == y.nmbase && x.n == y.n;

@@ -350,13 +350,21 @@ int target_batch_step_sequence(target_batch_c* b, long n_ticks, double dt, const
   });
 }
 
+int target_batch_step_sequence_ring(target_batch_c* b, long n_ticks, double dt, const void* meas_dev, long tick_stride, long ld,
+                                    const unsigned char* has_meas_dev, long has_stride, long ring_ticks, int use_graph) {
+  return guarded("target_batch_step_sequence_ring", [&] {
+    if (ring_ticks <= 0) throw std::invalid_argument("ring_ticks must be positive");
+    B(b)->step_sequence(n_ticks, dt, meas_dev, tick_stride, ld, has_meas_dev, has_stride, use_graph, ring_ticks);
+  });
+}
+
 int target_manager_step_sequence_all(target_manager_c* m, long n_ticks, double dt, const target_batch_sequence_c* per_batch,
                                      long n_batches, int query, const double* origin, double radius, int use_graph) {
   return guarded("target_manager_step_sequence_all", [&] {
     std::vector<te::Batch::SeqSpec> specs((size_t)(n_batches > 0 ? n_batches : 0));
     for (long i = 0; i < n_batches; ++i) {
       const target_batch_sequence_c& s = per_batch[i];
-      specs[(size_t)i] = te::Batch::SeqSpec{s.meas_dev, s.tick_stride, s.ld, s.has_meas_dev, s.has_stride, s.delta_dev, s.pose_dev};
+      specs[(size_t)i] = te::Batch::SeqSpec{s.meas_dev, s.tick_stride, s.ld, s.has_meas_dev, s.has_stride, s.delta_dev, s.pose_dev, s.ring_ticks};
     }
     M(m)->stepSequenceAll(n_ticks, dt, specs.data(), n_batches, query != 0, origin, radius, use_graph);
   });

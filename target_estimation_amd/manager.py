@@ -81,17 +81,23 @@ class Batch:
             hp = has_meas.data_ptr()
         _check(self._lib.target_batch_step(self._h, float(dt), mp, ld, hp), "target_batch_step")
 
-    def step_sequence(self, dt, meas, has_meas=None, use_graph=False):
-        """meas: CUDA tensor [ticks, 7, ld]: one launch per tick, all enqueued by one C call."""
+    def step_sequence(self, dt, meas, has_meas=None, use_graph=False, n_ticks=None):
+        """meas: CUDA tensor [ticks, 7, ld]: one launch per tick, all enqueued by one C call.  n_ticks > ticks
+        treats meas (and has_meas) as a ring: tick s reads entry s % ticks."""
         assert meas.is_cuda and meas.dim() == 3 and meas.shape[1] == 7 and (meas.shape[2] == 1 or meas.stride(2) == 1)
         assert meas.dtype == self.torch_dtype() and meas.shape[2] >= self.size
         hp, hs = None, 0
         if has_meas is not None:
             assert has_meas.is_cuda and has_meas.dim() == 2 and has_meas.element_size() == 1
             hp, hs = has_meas.data_ptr(), has_meas.stride(0)
-        _check(self._lib.target_batch_step_sequence(self._h, meas.shape[0], float(dt), meas.data_ptr(), meas.stride(0),
-                                                     meas.stride(1), hp, hs, int(use_graph)),
-               "target_batch_step_sequence")
+        if n_ticks is None or n_ticks == meas.shape[0]:
+            _check(self._lib.target_batch_step_sequence(self._h, meas.shape[0], float(dt), meas.data_ptr(), meas.stride(0),
+                                                         meas.stride(1), hp, hs, int(use_graph)),
+                   "target_batch_step_sequence")
+        else:
+            _check(self._lib.target_batch_step_sequence_ring(self._h, int(n_ticks), float(dt), meas.data_ptr(), meas.stride(0),
+                                                              meas.stride(1), hp, hs, meas.shape[0], int(use_graph)),
+                   "target_batch_step_sequence_ring")
 
     def step_fused(self, dt, meas, has_meas=None):
         """meas: CUDA tensor [ticks, 7, ld]: all ticks in ONE launch (state stays in registers)."""
@@ -371,20 +377,22 @@ class TargetManager:
             "target_manager_intersect_sphere_converged_batch")
         return conv.astype(bool), pose, delta, filt
 
-    def step_sequence_all(self, dt, meas, has_meas=None, query=None, use_graph=True):
+    def step_sequence_all(self, dt, meas, has_meas=None, query=None, use_graph=True, n_ticks=None):
         """meas: one CUDA tensor [ticks, 7, ld] per batch (batches() order): `ticks` ticks of every batch, the
         batches' launch chains as concurrent branches of one hipGraph (use_graph) or eagerly.  query =
         (origin[3], radius, deltas, poses) adds the own-time sphere query of every target after every step;
         deltas[i] [size] and poses[i] [size, 7] (or None) are CUDA double tensors, overwritten every tick."""
         nb = len(meas)          # the library checks it against the number of batches
-        ticks = meas[0].shape[0] if nb else 0
+        ring = meas[0].shape[0] if nb else 0
+        ticks = ring if n_ticks is None else int(n_ticks)      # n_ticks > ring: the tensors are rings (tick s reads s % ring)
         specs = (capi.BatchSequence * max(nb, 1))()
         for i, t in enumerate(meas):
-            assert t.is_cuda and t.dim() == 3 and t.shape[0] == ticks and t.shape[1] == 7 and (t.shape[2] == 1 or t.stride(2) == 1)
+            assert t.is_cuda and t.dim() == 3 and t.shape[0] == ring and t.shape[1] == 7 and (t.shape[2] == 1 or t.stride(2) == 1)
             specs[i].meas_dev, specs[i].tick_stride, specs[i].ld = t.data_ptr(), t.stride(0), t.stride(1)
+            specs[i].ring_ticks = ring if ticks != ring else 0
             if has_meas is not None and has_meas[i] is not None:
                 h = has_meas[i]
-                assert h.is_cuda and h.dim() == 2 and h.element_size() == 1 and h.shape[0] == ticks
+                assert h.is_cuda and h.dim() == 2 and h.element_size() == 1 and h.shape[0] == ring
                 specs[i].has_meas_dev, specs[i].has_stride = h.data_ptr(), h.stride(0)
         origin, radius = None, 0.0
         if query is not None:

@@ -458,3 +458,33 @@ def test_concurrent_callers_of_the_scalar_abi(models):
     np.testing.assert_array_equal(xa, xb)
     np.testing.assert_array_equal(Pa, Pb)
     assert na == nb
+
+
+def test_sequence_over_a_measurement_ring(models):
+    """target_batch_step_sequence_ring: n ticks over a ring of r < n measurement ticks (tick s reads entry s % r),
+    eagerly and from one recorded graph, equal single steps bit for bit."""
+    from target_estimation_amd.streams import make_stream
+    name, N, dt, ring, total = "angular_rates", 300, 0.004, 5, 17
+    st = make_stream(te.MODEL_TYPES[name], N, ring, dt, 61, availability=0.8)
+    res = []
+    for mode in ("single", "eager", "graph", "all_eager", "all_graph"):
+        mgr = te.TargetManager(model_path(name), dtype="f32")
+        mgr.init_batch(np.arange(N, dtype=np.uint32), dt, 0.0, st["p0"].cpu().numpy())
+        b = mgr.batches()[0]
+        meas = st["meas"].to(b.torch_dtype()).contiguous()
+        if mode == "single":
+            for _ in range(2):                       # every call starts at ring entry 0
+                for s in range(total):
+                    b.step(dt, meas[s % ring], st["has_meas"][s % ring])
+        elif mode.startswith("all"):                 # the manager-level call takes rings too
+            for _ in range(2):
+                mgr.step_sequence_all(dt, [meas], has_meas=[st["has_meas"]], use_graph=(mode == "all_graph"), n_ticks=total)
+        else:
+            for _ in range(2):                       # the second call replays the recorded graph
+                b.step_sequence(dt, meas, st["has_meas"], use_graph=(mode == "graph"), n_ticks=total)
+        res.append(mgr.get_state_batch(np.arange(N, dtype=np.uint32)) + (mgr.getNumberMeasurements(0), mgr.getTime(0)))
+        mgr.close()
+    for other in res[1:]:
+        np.testing.assert_array_equal(other[0], res[0][0])
+        np.testing.assert_array_equal(other[1], res[0][1])
+        assert other[2] == res[0][2] and other[3] == pytest.approx(res[0][3])
