@@ -603,7 +603,7 @@ def main():
         base, _, mult = name.partition("x")            # "cfg5x8": 8 x the per-GPU share = all 10^6 targets on this GPU
         if base in MIXED:
             sc = int(mult) if mult else 1
-            r = run_mixed(te, torch, base, 640 if sc == 1 else 128, 64, dist, rank, world, scale=sc,
+            r = run_mixed(te, torch, base, 2048 if sc == 1 else 128, 256 if sc == 1 else 64, dist, rank, world, scale=sc,
                           launch_mode="graph" if args.launch_mode == "fused" else args.launch_mode)
             r["name"] = name
             if sc > 1:
