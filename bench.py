@@ -216,10 +216,13 @@ def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None,
     # every GRAPH_TICKS-tick block of the ring is one recorded hipGraph.  Default ring = one block; RINGS gives
     # the *_stream workloads a ring far larger than L2 + Infinity Cache, so that every tick's measurements come
     # from HBM itself.
+    # The block length adapts to --steps so that the timed region is whole blocks for any K: the largest
+    # divisor of K in [16, GRAPH_TICKS], else GRAPH_TICKS (the remainder is then enqueued launch by launch).
+    gb = GRAPH_TICKS
+    if steps % GRAPH_TICKS:
+        gb = next((g for g in range(min(GRAPH_TICKS, steps), 15, -1) if steps % g == 0), min(GRAPH_TICKS, steps))
     ring_want = RINGS.get(name, stream_ticks)
-    ticks = min(ring_want, steps + warmup)
-    if ticks > GRAPH_TICKS:
-        ticks -= ticks % GRAPH_TICKS
+    ticks = max(gb, min(ring_want, steps + warmup) // gb * gb)
     st = make_stream(mtype, n_targets, ticks, dt, seed + 1000 * rank, **VARIANTS.get(name, {}))
     has = st["has_meas"]    # [ticks, N] uint8 or None
     import numpy as np
@@ -229,10 +232,11 @@ def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None,
     meas = st["meas"].to(b.torch_dtype()).contiguous()   # [ticks, 7, N] in the batch precision
     del st
     torch.cuda.synchronize()
-    gb = min(GRAPH_TICKS, ticks)
     # A one-block ring of a small (launch-bound) batch is replayed GRAPH_PASSES times per recorded graph
     # (target_batch_step_sequence_ring): every graph launch costs ~8 us, a noticeable share of 64 x 2 us.
-    passes = GRAPH_PASSES if (launch_mode == "graph" and ticks == gb == GRAPH_TICKS and n_targets <= 200000) else 1
+    passes = 1
+    if launch_mode == "graph" and ticks == gb and n_targets <= 200000:
+        passes = next((q for q in range(GRAPH_PASSES, 0, -1) if steps % (gb * q) == 0), 1)
 
     # One launch of the step kernel per tick in every mode.  "python": one C-ABI call per tick;
     # "sequence": the launches of a block of ticks are enqueued by one C call
@@ -269,6 +273,7 @@ def run_workload(te, torch, name, steps, warmup, lanes, targets=None, dist=None,
         if passes > 1:
             b.step_sequence(dt, meas, has, use_graph=2, n_ticks=gb * passes)
     run_ticks(warmup)
+    done[0] = 0          # the timed region starts on a block boundary of the ring
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
