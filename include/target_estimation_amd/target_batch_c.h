@@ -163,6 +163,12 @@ long target_batch_slot_ids(target_batch_c* b, unsigned int* ids_out, long capaci
  *                 for all slots), or NULL for predict-only.  Linear models read rows 0..2 only.
  *   has_meas_dev: per-slot bytes, or NULL (every slot has a measurement). */
 int target_batch_step(target_batch_c* b, double dt, const void* meas_dev, long ld, const unsigned char* has_meas_dev);
+/* One tick of every slot from HOST measurements in SoA form and in the batch precision: row c of meas_soa_host
+ * (ld_host elements per row) = component c of [x y z qx qy qz qw] for slots 0..size-1.  Only the rows the model
+ * reads are copied (3 for the linear models, 7 for the angular ones): 12-24 B per target over PCIe instead of the
+ * 56 B of target_manager_update_meas_batch's double[n][7], and no conversion kernel.  has_meas_host [size] or
+ * NULL.  Returns after the step has been enqueued and the host arrays have been consumed. */
+int target_batch_step_host(target_batch_c* b, double dt, const void* meas_soa_host, long ld_host, const unsigned char* has_meas_host);
 /* n_ticks consecutive ticks = n_ticks launches of the step kernel, enqueued in one call: tick s
  * reads meas_dev + s * tick_stride elements (and has_meas_dev + s * has_stride bytes).  With
  * use_graph != 0 the launches are recorded once into a hipGraph (keyed by the arguments) and

@@ -90,6 +90,7 @@ SIGNATURES = {
     "target_batch_resident_bytes_per_target": (C.c_double, [C.c_void_p]),
     "target_batch_slot_ids": (C.c_long, [C.c_void_p, c_uint_p, C.c_long]),
     "target_batch_step": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_long, C.c_void_p]),
+    "target_batch_step_host": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_long, C.c_void_p]),
     "target_batch_step_sequence": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_int]),
     "target_batch_step_sequence_ring": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_int]),
     "target_manager_step_sequence_all": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_long, C.c_int, c_double_p, C.c_double, C.c_int]),

@@ -346,6 +346,23 @@ void Batch::step_dense_host(double dt, const double* meas_aos, const unsigned ch
   TE_HIP_CHECK(hipStreamSynchronize(stream_));  // caller's host arrays may be reused after return
 }
 
+void Batch::step_dense_host_soa(double dt, const void* meas_soa, long ld_host, const unsigned char* has) {
+  touch();
+  if (n_ == 0) return;
+  stage_reserve(n_);
+  if (meas_soa) {
+    const bool angular = (type_ == ANGULAR_RATES || type_ == ANGULAR_VELOCITIES);
+    const size_t es = elem_size();
+    // rows of the device staging block are stage_cap_ elements apart
+    TE_HIP_CHECK(hipMemcpy2DAsync(d_meas_, (size_t)stage_cap_ * es, meas_soa, (size_t)ld_host * es, (size_t)n_ * es,
+                                  angular ? 7 : 3, hipMemcpyHostToDevice, stream_));
+  }
+  if (has) TE_HIP_CHECK(hipMemcpyAsync(d_mask_, has, (size_t)n_, hipMemcpyHostToDevice, stream_));
+  step_dense(dt, meas_soa ? d_meas_ : nullptr, stage_cap_, (meas_soa && has) ? d_mask_ : nullptr);
+  TE_HIP_CHECK(hipGetLastError());
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));  // caller's host arrays may be reused after return
+}
+
 void Batch::step_one(long slot, double dt, const double* meas7) {
   if (pending_mark_.size() < (size_t)n_) pending_mark_.resize((size_t)n_, 0);
   if (pending_mark_[(size_t)slot]) flush();   // second step of the same target: keep the caller's order

@@ -71,6 +71,10 @@ class Batch {
   void flush();
   // One tick over every slot in slot order, host inputs (rows of meas_aos / has follow the slot order)
   void step_dense_host(double dt, const double* meas_aos, const unsigned char* has);
+  // The same from SoA host rows in the BATCH precision (row c of meas_soa = component c of every slot,
+  // ld_host elements apart): only the rows the model reads cross PCIe (3 for the linear models, 7 for the
+  // angular ones) and no conversion kernel runs.  Pinned host memory makes the copies asynchronous DMA.
+  void step_dense_host_soa(double dt, const void* meas_soa, long ld_host, const unsigned char* has);
 
   // Derived outputs to host arrays; slots == null means all slots in order.
   void outputs(const int* slots, long n, double* pose, double* twist, double* acc, bool at_time, double t1);

@@ -343,6 +343,10 @@ int target_batch_step(target_batch_c* b, double dt, const void* meas_dev, long l
   return guarded("target_batch_step", [&] { B(b)->step_dense(dt, meas_dev, ld, has_meas_dev); });
 }
 
+int target_batch_step_host(target_batch_c* b, double dt, const void* meas_soa_host, long ld_host, const unsigned char* has_meas_host) {
+  return guarded("target_batch_step_host", [&] { B(b)->step_dense_host_soa(dt, meas_soa_host, ld_host, has_meas_host); });
+}
+
 int target_batch_step_sequence(target_batch_c* b, long n_ticks, double dt, const void* meas_dev, long tick_stride, long ld,
                                const unsigned char* has_meas_dev, long has_stride, int use_graph) {
   return guarded("target_batch_step_sequence", [&] {

@@ -81,6 +81,19 @@ class Batch:
             hp = has_meas.data_ptr()
         _check(self._lib.target_batch_step(self._h, float(dt), mp, ld, hp), "target_batch_step")
 
+    def step_host(self, dt, meas_soa, has_meas=None):
+        """One tick from HOST measurements: meas_soa = CPU tensor or ndarray [rows >= 3 or 7, ld] in the batch
+        precision (SoA; pinned memory gives asynchronous DMA), has_meas = CPU uint8 [size] or None."""
+        import torch
+        t = meas_soa if isinstance(meas_soa, torch.Tensor) else torch.from_numpy(meas_soa)
+        assert not t.is_cuda and t.dim() == 2 and t.stride(1) == 1 and t.dtype == self.torch_dtype() and t.shape[1] >= self.size
+        hp = None
+        if has_meas is not None:
+            h = has_meas if isinstance(has_meas, torch.Tensor) else torch.from_numpy(has_meas)
+            assert not h.is_cuda and h.element_size() == 1 and h.numel() >= self.size
+            hp = h.data_ptr()
+        _check(self._lib.target_batch_step_host(self._h, float(dt), t.data_ptr(), t.stride(0), hp), "target_batch_step_host")
+
     def step_sequence(self, dt, meas, has_meas=None, use_graph=False, n_ticks=None):
         """meas: CUDA tensor [ticks, 7, ld]: one launch per tick, all enqueued by one C call.  n_ticks > ticks
         treats meas (and has_meas) as a ring: tick s reads entry s % ticks."""

@@ -488,3 +488,34 @@ def test_sequence_over_a_measurement_ring(models):
         np.testing.assert_array_equal(other[0], res[0][0])
         np.testing.assert_array_equal(other[1], res[0][1])
         assert other[2] == res[0][2] and other[3] == pytest.approx(res[0][3])
+
+
+@pytest.mark.parametrize("name,dtype", [("uniform_acceleration", "f32"), ("angular_velocities", "f64")])
+def test_host_fed_soa_step_equals_device_step(models, name, dtype):
+    """target_batch_step_host (SoA host rows in the batch precision, only the rows the model reads cross PCIe) ==
+    target_batch_step on the same values already on the device, with and without a mask, pinned or pageable."""
+    from target_estimation_amd.streams import make_stream
+    N, dt, ticks = 777, 0.004, 6
+    st = make_stream(te.MODEL_TYPES[name], N, ticks, dt, 71, availability=0.7)
+    res = []
+    for mode in ("device", "host"):
+        mgr = te.TargetManager(model_path(name), dtype=dtype)
+        mgr.init_batch(np.arange(N, dtype=np.uint32), dt, 0.0, st["p0"].cpu().numpy())
+        b = mgr.batches()[0]
+        meas = st["meas"].to(b.torch_dtype()).contiguous()
+        for s in range(ticks):
+            mask = st["has_meas"][s] if s % 2 else None
+            if mode == "device":
+                b.step(dt, meas[s], mask)
+            else:
+                rows = meas[s].cpu()
+                if s % 3 == 0:
+                    rows = rows.pin_memory()
+                if name == "uniform_acceleration" and s % 2:
+                    rows = rows[:3].contiguous()             # the linear models only need x, y, z
+                b.step_host(dt, rows, None if mask is None else mask.cpu())
+        res.append(mgr.get_state_batch(np.arange(N, dtype=np.uint32)) + (mgr.getNumberMeasurements(5),))
+        mgr.close()
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2]

@@ -64,6 +64,14 @@ def main():
             b.step(0.004, dev)
         torch.cuda.synchronize()
         tc = (time.perf_counter() - t0) / args.ticks
+        rows = pinned if args.model.startswith("angular") else pinned[:3].contiguous().pin_memory()
+        b.step_host(0.004, rows)
+        t0 = time.perf_counter()
+        for _ in range(args.ticks):
+            b.step_host(0.004, rows)
+        th = (time.perf_counter() - t0) / args.ticks
+        print("%s %s N=%d: target_batch_step_host (pinned SoA rows in the batch precision, %d rows) %.1f us/tick (%.3g cycles/s)"
+              % (args.model, args.dtype, n, rows.shape[0], th * 1e6, n / th), flush=True)
         print("%s %s N=%d: by-ids host arrays %.1f us/tick (%.3g cycles/s) | pinned SoA H2D + step %.1f us/tick (%.3g cycles/s) | device-resident %.1f us/tick (%.3g cycles/s)"
               % (args.model, args.dtype, n, ta * 1e6, n / ta, tb * 1e6, n / tb, tc * 1e6, n / tc), flush=True)
         mgr.close()
