@@ -213,6 +213,13 @@ int target_batch_intersect_sphere_dev(target_batch_c* b, double t1, const double
 int target_batch_intersect_sphere_converged_dev(target_batch_c* b, double t1, double pos_th, double ang_th,
                                                 const double* origin, double radius, int filters_length,
                                                 double* delta_dev, double* pose_dev, unsigned char* converged_dev);
+/* The convergence gate alone (IntersectionSolver::getIntersectionPoseWithSphere, src/intersection_solver.cpp:102-120),
+ * fed with query results already on the device -- e.g. the delta / pose arrays the per-tick query of
+ * target_manager_step_sequence_all leaves behind: delta_dev [size], pose_dev [size][7] -> converged_dev [size];
+ * filtered_dev [size][2] (filtered position / angle error) and variance_dev [size][2]
+ * (MovingAvgFilter::getVariance, utils.hpp:241-251; O(filters_length) per target, NULL skips it) are optional. */
+int target_batch_gate_update_dev(target_batch_c* b, const double* delta_dev, const double* pose_dev, double pos_th, double ang_th,
+                                 int filters_length, unsigned char* converged_dev, double* filtered_dev, double* variance_dev);
 /* AoS doubles [n][7] (host layout of the reference) -> SoA [7][ld] in the batch precision, on device */
 int target_batch_pack_meas_dev(target_batch_c* b, const double* meas_aos_dev, long n, void* meas_soa_dev, long ld);
 

@@ -67,6 +67,7 @@ SIGNATURES = {
                                                                    c_ubyte_p, c_ubyte_p, c_double_p]),
     "target_batch_intersect_sphere_converged_dev": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, c_double_p, C.c_double,
                                                               C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "target_batch_gate_update_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "target_batch_intersect_sphere_dev": (C.c_int, [C.c_void_p, C.c_double, c_double_p, C.c_double, C.c_void_p, C.c_void_p]),
     "target_ingest_new": (C.c_void_p, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p]),
     "target_ingest_delete": (None, [C.c_void_p]),

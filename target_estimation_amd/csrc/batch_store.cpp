@@ -21,8 +21,8 @@ const Ops* get_ops(int type, int dtype, int g) {
   }
 }
 
-Batch::Batch(int type, int dtype, int lanes, const double* Q, const double* R, hipStream_t stream)
-    : type_(type), dtype_(dtype), lanes_code_(lanes), ops_(get_ops(type, dtype, lanes)), stream_(stream) {
+Batch::Batch(int type, int dtype, int lanes, const double* Q, const double* R, hipStream_t stream, std::mutex* owner_lock)
+    : type_(type), dtype_(dtype), lanes_code_(lanes), owner_lock_(owner_lock), ops_(get_ops(type, dtype, lanes)), stream_(stream) {
   if (!ops_) throw std::runtime_error("target_estimation_amd: unsupported (model, precision, lanes-per-target) combination");
   const int n = ops_->L.n, m = ops_->L.m;
   Q_.assign(Q, Q + n * n);
@@ -74,8 +74,11 @@ long Batch::algorithmic_bytes_per_cycle() const {
       for (int c = (ops_->L.layout == LAYOUT_SEPARABLE_PACKED ? r : 0); c < n; ++c)
         pwords += group_of(type_, r) == group_of(type_, c) ? 2 : 0;
   }
-  return (2 * n + pwords + 7 + (angular ? 6 : 0)) * (long)elem_size();
+  // measurement words the step kernel READS: [x y z] for the linear models, [x y z qx qy qz qw] for the angular
+  // ones (kf_step_sep.hpp MW, kf_step.hpp ymeas_own/qmeas); SURVEY 8d's formula charges 7 for every model
+  return (2 * n + pwords + (angular ? 7 + 6 : 3)) * (long)elem_size();
 }
+
 
 void Batch::reserve(long n) {
   if (n <= cap_) return;
@@ -257,9 +260,20 @@ void Batch::step_sequence(long n_ticks, double dt, const void* meas_base, long t
       if (!cap_stream_) TE_HIP_CHECK(hipStreamCreateWithFlags(&cap_stream_, hipStreamNonBlocking));
       GraphEntry e{n_ticks, tick_stride, ld, has_stride, n_, dt, meas_base, has_base, d_rec_, nullptr, nullptr, ring_ticks};
       TE_HIP_CHECK(hipStreamBeginCapture(cap_stream_, hipStreamCaptureModeThreadLocal));
-      for (long s = 0; s < n_ticks; ++s) ops_->step(params(s), cap_stream_);
+      try {
+        for (long s = 0; s < n_ticks; ++s) ops_->step(params(s), cap_stream_);
+        TE_HIP_CHECK(hipGetLastError());
+      } catch (...) {
+        hipGraph_t broken = nullptr;
+        (void)hipStreamEndCapture(cap_stream_, &broken);   // never leave the stream in capture mode
+        if (broken) (void)hipGraphDestroy(broken);
+        throw;
+      }
       TE_HIP_CHECK(hipStreamEndCapture(cap_stream_, &e.graph));
-      TE_HIP_CHECK(hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
+      if (hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGraphDestroy(e.graph);
+        throw std::runtime_error("target_estimation_amd: hipGraphInstantiate failed for a step sequence");
+      }
       graphs_.push_back(e);
       hit = &graphs_.back();
     }
@@ -349,6 +363,7 @@ void Batch::step_dense_host(double dt, const double* meas_aos, const unsigned ch
 void Batch::step_dense_host_soa(double dt, const void* meas_soa, long ld_host, const unsigned char* has) {
   touch();
   if (n_ == 0) return;
+  if (meas_soa && ld_host < n_) throw std::invalid_argument("target_estimation_amd: step_host: the row stride of the host measurements is smaller than the batch");
   stage_reserve(n_);
   if (meas_soa) {
     const bool angular = (type_ == ANGULAR_RATES || type_ == ANGULAR_VELOCITIES);
@@ -578,6 +593,7 @@ void Batch::intersect_gated(const int* slots, long n, double t1, const double* o
   g.idx = a.idx; g.n = n; g.window = gate_window_; g.delta = a.delta; g.pose = a.pose; g.pos_th = pos_th; g.ang_th = ang_th;
   g.ring = d_gate_ring_; g.sum = d_gate_sum_; g.state = d_gate_state_; g.prev = d_gate_prev_;
   g.converged = d_mask_; g.filt = filt ? d_aos_ + 8 * n : nullptr;   // [n][2] after delta + pose
+  g.var = nullptr;
   hipLaunchKernelGGL(gate_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream_, g);
   TE_HIP_CHECK(hipGetLastError());
   if (delta) TE_HIP_CHECK(hipMemcpyAsync(delta, a.delta, sizeof(double) * n, hipMemcpyDeviceToHost, stream_));
@@ -590,12 +606,19 @@ void Batch::intersect_gated(const int* slots, long n, double t1, const double* o
 void Batch::intersect_gated_dev(double t1, const double* origin, double radius, double pos_th, double ang_th, int window,
                                 double* delta_dev, double* pose_dev, unsigned char* converged_dev) {
   if (n_ == 0) return;
-  gate_reserve(window);
   intersect_dev(t1, origin, radius, delta_dev, pose_dev);
+  gate_update_dev(delta_dev, pose_dev, pos_th, ang_th, window, converged_dev, nullptr, nullptr);
+}
+
+void Batch::gate_update_dev(const double* delta_dev, const double* pose_dev, double pos_th, double ang_th, int window,
+                            unsigned char* converged_dev, double* filt_dev, double* var_dev) {
+  flush();
+  if (n_ == 0) return;
+  gate_reserve(window);
   GateArgs g;
   g.idx = nullptr; g.n = n_; g.window = gate_window_; g.delta = delta_dev; g.pose = pose_dev; g.pos_th = pos_th; g.ang_th = ang_th;
   g.ring = d_gate_ring_; g.sum = d_gate_sum_; g.state = d_gate_state_; g.prev = d_gate_prev_;
-  g.converged = converged_dev; g.filt = nullptr;
+  g.converged = converged_dev; g.filt = filt_dev; g.var = var_dev;
   hipLaunchKernelGGL(gate_kernel, dim3((unsigned)((n_ + 127) / 128)), dim3(128), 0, stream_, g);
   TE_HIP_CHECK(hipGetLastError());
 }

@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -16,11 +17,14 @@ namespace te {
 
 class Batch {
  public:
-  Batch(int type, int dtype, int lanes, const double* Q, const double* R, hipStream_t stream);
+  // `owner_lock`: the mutex of the manager that owns the batch (TargetManager::target_lock_); the C boundary takes it
+  // around every call made through a batch handle, so that those calls and the manager's own are serialised
+  Batch(int type, int dtype, int lanes, const double* Q, const double* R, hipStream_t stream, std::mutex* owner_lock = nullptr);
   ~Batch();
   Batch(const Batch&) = delete;
   Batch& operator=(const Batch&) = delete;
 
+  std::mutex* owner_lock() const { return owner_lock_; }
   int type() const { return type_; }
   int lanes_code() const { return lanes_code_; }
   int dtype() const { return dtype_; }
@@ -97,6 +101,10 @@ class Batch {
                        double ang_th, int window, double* delta, double* pose, unsigned char* converged, double* filt);
   void intersect_gated_dev(double t1, const double* origin, double radius, double pos_th, double ang_th, int window,
                            double* delta_dev, double* pose_dev, unsigned char* converged_dev);
+  // the gate alone, fed with query results that are already on the device (e.g. the outputs of the per-tick query
+  // fused into the step kernels): every slot, delta [size], pose [size][7]; filt / var [size][2] optional
+  void gate_update_dev(const double* delta_dev, const double* pose_dev, double pos_th, double ang_th, int window,
+                       unsigned char* converged_dev, double* filt_dev, double* var_dev);
 
   // Building blocks of the manager's all-batches sequence (TargetManager::stepSequenceAll): enqueue
   // n_ticks ticks -- each optionally followed by the own-time sphere query of every slot -- on `st`
@@ -134,6 +142,7 @@ class Batch {
   void upload_slots(const int* slots, long n);
 
   int type_, dtype_, lanes_code_;
+  std::mutex* owner_lock_ = nullptr;
   const Ops* ops_;
   hipStream_t stream_;
   std::vector<double> Q_, R_;

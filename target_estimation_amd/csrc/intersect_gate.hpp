@@ -27,14 +27,17 @@ struct GateArgs {
   double* prev;              // [cap][7]
   unsigned char* converged;  // [n]
   double* filt;              // [n][2] filtered errors, or null
+  double* var;               // [n][2] MovingAvgFilter::getVariance() of the two filters, or null (O(W) per query)
 };
 
 // geometry.hpp:79-88
 __device__ __forceinline__ double wrap_max_d(double x, double mx) { return ::fmod(mx + ::fmod(x, mx), mx); }
 __device__ __forceinline__ double wrap_min_max_d(double x, double mn, double mx) { return mn + wrap_max_d(x - mn, mx - mn); }
 
-// MovingAvgFilter::update, utils.hpp:222-251 (the variance it also computes is never read by the solver)
-__device__ __forceinline__ double moving_avg_update(double* ring, double* sum, int* state, int W, double value) {
+// MovingAvgFilter::update, utils.hpp:222-251.  The variance it also computes (:241-246: over EVERY window entry,
+// the still-unfilled zeros included, divided by the number of samples seen) is never read by the solver; it is
+// evaluated only when the caller asks for it (var != null).
+__device__ __forceinline__ double moving_avg_update(double* ring, double* sum, int* state, int W, double value, double* var = nullptr) {
   int idx = *state & 0x3fffffff;
   int complete = (*state >> 30) & 1;
   double s = *sum;
@@ -47,6 +50,11 @@ __device__ __forceinline__ double moving_avg_update(double* ring, double* sum, i
   idx = (idx + 1) % W;
   *sum = s;
   *state = idx | (complete << 30);
+  if (var) {
+    double vs = 0.0;
+    for (int k = 0; k < W; ++k) { const double d = ring[k] - res; vs += d * d; }
+    *var = vs / num;
+  }
   return res;
 }
 
@@ -75,8 +83,10 @@ __global__ void gate_kernel(const GateArgs a) {
     quat_normalize(qe);
     const double pi = 3.14159265358979323846;
     const double ang_error = ::fabs(wrap_min_max_d(2 * ::acos(qe[3]), -pi, pi));   // :110
-    pf = moving_avg_update(a.ring + (slot * 2 + 0) * a.window, a.sum + slot * 2 + 0, a.state + slot * 2 + 0, a.window, pos_error);
-    af = moving_avg_update(a.ring + (slot * 2 + 1) * a.window, a.sum + slot * 2 + 1, a.state + slot * 2 + 1, a.window, ang_error);
+    pf = moving_avg_update(a.ring + (slot * 2 + 0) * a.window, a.sum + slot * 2 + 0, a.state + slot * 2 + 0, a.window, pos_error,
+                           a.var ? a.var + e * 2 : nullptr);
+    af = moving_avg_update(a.ring + (slot * 2 + 1) * a.window, a.sum + slot * 2 + 1, a.state + slot * 2 + 1, a.window, ang_error,
+                           a.var ? a.var + e * 2 + 1 : nullptr);
     for (int c = 0; c < 7; ++c) prev[c] = p[c];                   // :117
     conv = (pf <= a.pos_th && af <= a.ang_th);                    // :119
   }

@@ -142,7 +142,7 @@ int TargetManager::chooseLayout(int type, const double* Q, const double* R, cons
 int TargetManager::findOrCreateBatch(int type, const double* Q, const double* R, int lanes_code) {
   for (size_t b = 0; b < batches_.size(); ++b)
     if (batches_[b]->same_params(type, Q, R) && batches_[b]->lanes_code() == lanes_code) return (int)b;
-  batches_.emplace_back(new Batch(type, dtype_, lanes_code, Q, R, stream_));
+  batches_.emplace_back(new Batch(type, dtype_, lanes_code, Q, R, stream_, &target_lock_));
   return (int)batches_.size() - 1;
 }
 
@@ -769,6 +769,7 @@ void TargetManager::stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpe
 }
 
 void TargetManager::synchronize() {
+  lock_guard<mutex> lg(target_lock_);
   for (auto& b : batches_) b->synchronize();
 }
 

@@ -4,6 +4,7 @@
 // extension declared in include/target_estimation_amd/target_batch_c.h.
 #include <cstdio>
 #include <exception>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -56,6 +57,12 @@ inline Batch* B(target_batch_c* b) {
   if (!b) throw std::invalid_argument("NULL batch handle");
   return (Batch*)b;
 }
+// Calls through a batch handle take the owning manager's mutex (the same one every TargetManager method takes), so a
+// thread on the ten-symbol ABI and a thread driving a batch handle are serialised; Batch itself is not locked.
+struct BatchLock {
+  std::unique_lock<std::mutex> l;
+  explicit BatchLock(Batch* b) { if (b->owner_lock()) l = std::unique_lock<std::mutex>(*b->owner_lock()); }
+};
 inline te::MeasurementIngest* I(target_ingest_c* i) {
   if (!i) throw std::invalid_argument("NULL ingest handle");
   return (te::MeasurementIngest*)i;
@@ -271,15 +278,24 @@ long target_manager_intersect_sphere_converged_batch(target_manager_c* self, con
 int target_batch_intersect_sphere_converged_dev(target_batch_c* b, double t1, double pos_th, double ang_th,
                                                 const double* origin, double radius, int filters_length,
                                                 double* delta_dev, double* pose_dev, unsigned char* converged_dev) {
-  return guarded("target_batch_intersect_sphere_converged_dev", [&] {
+  return guarded("target_batch_intersect_sphere_converged_dev", [&] { BatchLock lk(B(b));
     B(b)->intersect_gated_dev(t1, origin, radius, pos_th, ang_th, filters_length > 0 ? filters_length : 250, delta_dev,
                               pose_dev, converged_dev);
   });
 }
 
+int target_batch_gate_update_dev(target_batch_c* b, const double* delta_dev, const double* pose_dev, double pos_th, double ang_th,
+                                 int filters_length, unsigned char* converged_dev, double* filtered_dev, double* variance_dev) {
+  return guarded("target_batch_gate_update_dev", [&] { BatchLock lk(B(b));
+    if (!delta_dev || !pose_dev || !converged_dev) throw std::invalid_argument("delta, pose and converged are required");
+    B(b)->gate_update_dev(delta_dev, pose_dev, pos_th, ang_th, filters_length > 0 ? filters_length : 250, converged_dev, filtered_dev,
+                          variance_dev);
+  });
+}
+
 int target_batch_intersect_sphere_dev(target_batch_c* b, double t1, const double* origin, double radius,
                                       double* delta_dev, double* pose_dev) {
-  return guarded("target_batch_intersect_sphere_dev", [&] { B(b)->intersect_dev(t1, origin, radius, delta_dev, pose_dev); });
+  return guarded("target_batch_intersect_sphere_dev", [&] { BatchLock lk(B(b)); B(b)->intersect_dev(t1, origin, radius, delta_dev, pose_dev); });
 }
 
 int target_manager_num_batches(target_manager_c* self) {
@@ -332,6 +348,7 @@ double target_batch_resident_bytes_per_target(target_batch_c* b) {
 
 long target_batch_slot_ids(target_batch_c* b, unsigned int* ids_out, long capacity) {
   return guarded_value<long>("target_batch_slot_ids", -1, [&]() -> long {
+    BatchLock lk(B(b));
     const auto& ids = B(b)->slot_ids();
     const long n = (long)ids.size();
     for (long i = 0; i < n && i < capacity; ++i) ids_out[i] = ids[(size_t)i];
@@ -340,23 +357,23 @@ long target_batch_slot_ids(target_batch_c* b, unsigned int* ids_out, long capaci
 }
 
 int target_batch_step(target_batch_c* b, double dt, const void* meas_dev, long ld, const unsigned char* has_meas_dev) {
-  return guarded("target_batch_step", [&] { B(b)->step_dense(dt, meas_dev, ld, has_meas_dev); });
+  return guarded("target_batch_step", [&] { BatchLock lk(B(b)); B(b)->step_dense(dt, meas_dev, ld, has_meas_dev); });
 }
 
 int target_batch_step_host(target_batch_c* b, double dt, const void* meas_soa_host, long ld_host, const unsigned char* has_meas_host) {
-  return guarded("target_batch_step_host", [&] { B(b)->step_dense_host_soa(dt, meas_soa_host, ld_host, has_meas_host); });
+  return guarded("target_batch_step_host", [&] { BatchLock lk(B(b)); B(b)->step_dense_host_soa(dt, meas_soa_host, ld_host, has_meas_host); });
 }
 
 int target_batch_step_sequence(target_batch_c* b, long n_ticks, double dt, const void* meas_dev, long tick_stride, long ld,
                                const unsigned char* has_meas_dev, long has_stride, int use_graph) {
-  return guarded("target_batch_step_sequence", [&] {
+  return guarded("target_batch_step_sequence", [&] { BatchLock lk(B(b));
     B(b)->step_sequence(n_ticks, dt, meas_dev, tick_stride, ld, has_meas_dev, has_stride, use_graph);
   });
 }
 
 int target_batch_step_sequence_ring(target_batch_c* b, long n_ticks, double dt, const void* meas_dev, long tick_stride, long ld,
                                     const unsigned char* has_meas_dev, long has_stride, long ring_ticks, int use_graph) {
-  return guarded("target_batch_step_sequence_ring", [&] {
+  return guarded("target_batch_step_sequence_ring", [&] { BatchLock lk(B(b));
     if (ring_ticks <= 0) throw std::invalid_argument("ring_ticks must be positive");
     B(b)->step_sequence(n_ticks, dt, meas_dev, tick_stride, ld, has_meas_dev, has_stride, use_graph, ring_ticks);
   });
@@ -376,17 +393,17 @@ int target_manager_step_sequence_all(target_manager_c* m, long n_ticks, double d
 
 int target_batch_step_fused(target_batch_c* b, long n_ticks, double dt, const void* meas_dev, long tick_stride, long ld,
                             const unsigned char* has_meas_dev, long has_stride) {
-  return guarded("target_batch_step_fused", [&] {
+  return guarded("target_batch_step_fused", [&] { BatchLock lk(B(b));
     B(b)->step_fused(n_ticks, dt, meas_dev, tick_stride, ld, has_meas_dev, has_stride);
   });
 }
 
 int target_batch_get_est_dev(target_batch_c* b, double* pose_dev, double* twist_dev, double* acc_dev, int at_time, double t1) {
-  return guarded("target_batch_get_est_dev", [&] { B(b)->outputs_dev(pose_dev, twist_dev, acc_dev, at_time != 0, t1); });
+  return guarded("target_batch_get_est_dev", [&] { BatchLock lk(B(b)); B(b)->outputs_dev(pose_dev, twist_dev, acc_dev, at_time != 0, t1); });
 }
 
 int target_batch_pack_meas_dev(target_batch_c* b, const double* meas_aos_dev, long n, void* meas_soa_dev, long ld) {
-  return guarded("target_batch_pack_meas_dev", [&] { B(b)->pack_meas_dev(meas_aos_dev, n, meas_soa_dev, ld); });
+  return guarded("target_batch_pack_meas_dev", [&] { BatchLock lk(B(b)); B(b)->pack_meas_dev(meas_aos_dev, n, meas_soa_dev, ld); });
 }
 
 // ---------------------------------------------------------------- measurement ingest

@@ -83,10 +83,12 @@ class Batch:
 
     def step_host(self, dt, meas_soa, has_meas=None):
         """One tick from HOST measurements: meas_soa = CPU tensor or ndarray [rows >= 3 or 7, ld] in the batch
-        precision (SoA; pinned memory gives asynchronous DMA), has_meas = CPU uint8 [size] or None."""
+        precision (SoA; rows >= 7 for the angular models; pinned memory gives asynchronous DMA), has_meas = CPU uint8 [size] or None."""
         import torch
         t = meas_soa if isinstance(meas_soa, torch.Tensor) else torch.from_numpy(meas_soa)
         assert not t.is_cuda and t.dim() == 2 and t.stride(1) == 1 and t.dtype == self.torch_dtype() and t.shape[1] >= self.size
+        need = 7 if self.type in (ANGULAR_RATES, ANGULAR_VELOCITIES) else 3   # rows the model reads (and the copy moves)
+        assert t.shape[0] >= need, "this model reads %d measurement rows, got %d" % (need, t.shape[0])
         hp = None
         if has_meas is not None:
             h = has_meas if isinstance(has_meas, torch.Tensor) else torch.from_numpy(has_meas)
@@ -158,6 +160,21 @@ class Batch:
             self._h, float("nan") if t1 is None else float(t1), float(pos_th), float(ang_th), _dp(origin), float(radius),
             int(filters_length), delta.data_ptr(), pose.data_ptr(), conv.data_ptr()), "target_batch_intersect_sphere_converged_dev")
         return conv, pose, delta
+
+    def gate_update(self, delta, pose, pos_th, ang_th, filters_length=250, want_variance=False):
+        """The convergence gate alone on query results already on the device (delta [size], pose [size,7], CUDA doubles):
+        returns converged [size] uint8, filtered errors [size,2] and, on request, the filters' variances [size,2]."""
+        import torch
+        n = self.size
+        assert delta.is_cuda and pose.is_cuda and delta.dtype == torch.float64 and pose.dtype == torch.float64
+        assert delta.numel() >= n and pose.is_contiguous() and pose.shape[0] >= n and pose.shape[1] == 7
+        conv = torch.empty(n, dtype=torch.uint8, device="cuda")
+        filt = torch.empty((n, 2), dtype=torch.float64, device="cuda")
+        var = torch.empty((n, 2), dtype=torch.float64, device="cuda") if want_variance else None
+        _check(self._lib.target_batch_gate_update_dev(self._h, delta.data_ptr(), pose.data_ptr(), float(pos_th), float(ang_th),
+                                                       int(filters_length), conv.data_ptr(), filt.data_ptr(),
+                                                       None if var is None else var.data_ptr()), "target_batch_gate_update_dev")
+        return conv, filt, var
 
     def pack_meas(self, meas_aos, out=None):
         """CUDA double [n,7] (the reference's row layout) -> SoA [7,n] in the batch precision."""

@@ -200,7 +200,7 @@ def test_reference_harness_in_fp32(models, harness_stream, name):
     mgr.close()
 
 
-@pytest.mark.parametrize("wl", ["ar1m", "uv1m", "ar1m_full", "av1m_s201"])
+@pytest.mark.parametrize("wl", ["ar1m", "uv1m", "ar1m_full", "av1m_s201", "cfg3", "av1m", "ar1m64", "av1m64", "ua1m64"])
 def test_full_size_properties(models, wl):
     """BASELINE-size batches (10^6 targets): properties that do not need the oracle on every target
     (finite, covariance symmetric to rounding with positive diagonal, slot ids in order, predict-only
@@ -231,7 +231,7 @@ def test_full_size_properties(models, wl):
     pose, twist, acc = b.get_est()
     assert torch.isfinite(pose).all() and torch.isfinite(twist).all() and torch.isfinite(acc).all()
     np.testing.assert_array_equal(b.slot_ids()[::9973], ids[::9973])
-    tail = np.arange(N - 3000, N, dtype=np.uint32)                    # includes the last, partial tile
+    tail = np.arange(N - 3000, N, dtype=np.uint32)                    # includes the last (for 10^5: partial) tile
     x, P = mgr.get_state_batch(tail)
     assert np.isfinite(x).all() and np.isfinite(P).all()
     sym = np.abs(P - P.transpose(0, 2, 1)).max(axis=(1, 2)) / np.abs(P).max(axis=(1, 2))

@@ -188,3 +188,44 @@ def test_all_batches_sequence_equals_per_batch_calls(models, dtype, lanes, use_g
     with pytest.raises(RuntimeError):
         mgr.step_sequence_all(dt, meas2[:2])
     ref.close(); mgr.close()
+
+
+def test_gate_moving_averages_meet_the_reference_filter_test(models):
+    """test/avg_filter_test.cpp:30-41 on the GPU gate: MovingAvgFilter(1000) fed 10 000 samples of N(5, 1) must end
+    with mean within 0.1 of 5 and variance within 0.1 of 1.  The gate's position filter sees |p_k - p_{k-1}|, so the
+    intersection poses are laid out along x with N(5,1) increments (all positive at 5 sigma); the angle filter sees
+    0.  Also checked: the warm-up rule (mean over the samples seen so far until the window is full) and the
+    filtered value against NumPy's window mean, for 64 independent targets at once."""
+    N, W, n_meas = 64, 1000, 10000
+    name = "uniform_acceleration"
+    mgr = te.TargetManager(model_path(name))
+    p0 = np.tile([0, 0, 0, 0, 0, 0, 1.0], (N, 1))
+    mgr.init_batch(np.arange(N, dtype=np.uint32), 0.004, 0.0, p0)
+    b = mgr.batches()[0]
+    rng = np.random.default_rng(0)
+    inc = rng.normal(5.0, 1.0, (n_meas, N))
+    assert inc.min() > 0
+    x = np.cumsum(inc, axis=0)
+    pose = torch.zeros((N, 7), dtype=torch.float64, device="cuda")
+    pose[:, 6] = 1.0
+    delta = torch.zeros(N, dtype=torch.float64, device="cuda")      # "an intersection exists" for every target
+    xs = torch.from_numpy(x).cuda()
+    for k in range(n_meas):
+        pose[:, 0] = xs[k]
+        want_var = k == n_meas - 1 or k == 499
+        conv, filt, var = b.gate_update(delta, pose, 1e9, 1e9, filters_length=W, want_variance=want_var)
+        if k in (0, 1, 499, 999, 1000, 5000, n_meas - 1):
+            f = filt.cpu().numpy()
+            lo = max(0, k + 1 - W)
+            np.testing.assert_allclose(f[:, 0], inc[lo:k + 1].mean(axis=0), rtol=1e-10)
+            assert (f[:, 1] == 0).all() and conv.all()
+        if k == 499:   # the reference's variance while warming up counts the unfilled zeros of the window (utils.hpp:241-246)
+            res = inc[:500].mean(axis=0)
+            want = (((inc[:500] - res) ** 2).sum(axis=0) + 500 * res ** 2) / 500
+            np.testing.assert_allclose(var.cpu().numpy()[:, 0], want, rtol=1e-9)
+    mean, variance = filt.cpu().numpy()[:, 0], var.cpu().numpy()[:, 0]
+    assert np.abs(mean - 5.0).max() < 0.1 + 0.05        # 64 targets: the worst of 64 draws of a 0.032-sigma mean, the reference tests one
+    assert np.abs(mean[0] - 5.0) < 0.1                   # the reference's own assertion, first target (avg_filter_test.cpp:40)
+    assert np.abs(variance[0] - 1.0) < 0.1               # avg_filter_test.cpp:41
+    assert np.abs(variance - 1.0).max() < 0.2
+    mgr.close()
