@@ -16,7 +16,7 @@
 
 #include "target_manager_c.h"
 
-typedef void target_batch_c; /* all targets of one (model, Q, R) inside a manager */
+typedef void target_batch_c; /* all targets of one (model, P layout) inside a manager */
 
 /* model ids = the reference enum TargetManager::target_t (target_manager.hpp:38) */
 #define TARGET_ANGULAR_RATES 0
@@ -75,6 +75,15 @@ long target_manager_init_batch(target_manager_c* self, const unsigned int* ids, 
 long target_manager_init_batch_typed(target_manager_c* self, int type, const unsigned int* ids, long n, double dt0,
                                      double t0, const double* Q, const double* R, const double* P0,
                                      int per_target_P0, const double* p0, const double* v0, const double* a0);
+/* n targets whose model parameters come from a table of n_classes sets: Q [n_classes][ns*ns], R [n_classes][m*m],
+ * P0 [n_classes][ns*ns] (row-major), class_of [n] = the row of target i.  The reference lets every target carry its own
+ * Q, R, P0 (TargetManager::init, target_manager.hpp:85-87); here all classes of one layout live in ONE batch -- a (Q, R)
+ * table in HBM plus a class index per target -- so a tick is still one launch per motion model, however many classes
+ * there are.  (The one-set initialisers above do the same: a new (Q, R) for a model joins that model's batch as a new
+ * class.)  Existing ids are skipped.  Returns the number created (or < 0). */
+long target_manager_init_batch_classes(target_manager_c* self, int type, const unsigned int* ids, long n, double dt0, double t0,
+                                       long n_classes, const double* Q, const double* R, const double* P0,
+                                       const unsigned int* class_of, const double* p0, const double* v0, const double* a0);
 /* TargetManager::erase, target_manager.cpp:227-241.  1 = erased, 0 = unknown id. */
 int target_manager_erase(target_manager_c* self, unsigned int id);
 /* the same for n ids in one call: one compaction launch per batch instead of one launch per target
@@ -150,6 +159,8 @@ int target_batch_lanes_per_target(target_batch_c* b);
 int target_batch_is_symmetric_packed(target_batch_c* b);
 /* 0 full P, 1 symmetric-packed, 2 axis-separable, 3 axis-separable with symmetric-packed groups */
 int target_batch_layout(target_batch_c* b);
+/* number of distinct (Q, R) parameter classes among the batch's targets */
+int target_batch_num_classes(target_batch_c* b);
 /* bytes one predict+update cycle of one target must move ((2n + 2n^2 + 7 (+6)) * w, or
  * (2n + n(n+1) + 7 (+6)) * w for a symmetric-packed batch, (2n + 2 sum(group^2) + 7 (+6)) * w for an
  * axis-separable one) */

@@ -46,6 +46,9 @@ SIGNATURES = {
     "target_manager_init_batch_typed": (C.c_long, [C.c_void_p, C.c_int, c_uint_p, C.c_long, C.c_double, C.c_double,
                                                    c_double_p, c_double_p, c_double_p, C.c_int, c_double_p,
                                                    c_double_p, c_double_p]),
+    "target_manager_init_batch_classes": (C.c_long, [C.c_void_p, C.c_int, c_uint_p, C.c_long, C.c_double, C.c_double, C.c_long,
+                                                     c_double_p, c_double_p, c_double_p, c_uint_p, c_double_p, c_double_p, c_double_p]),
+    "target_batch_num_classes": (C.c_int, [C.c_void_p]),
     "target_manager_erase": (C.c_int, [C.c_void_p, C.c_uint]),
     "target_manager_erase_batch": (C.c_long, [C.c_void_p, C.POINTER(C.c_uint), C.c_long]),
     "target_manager_size": (C.c_long, [C.c_void_p]),

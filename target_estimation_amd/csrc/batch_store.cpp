@@ -5,6 +5,7 @@
 #include <cstring>
 #include <limits>
 #include <stdexcept>
+#include <string>
 
 #include "hip_check.hpp"
 #include "intersect_gate.hpp"
@@ -24,36 +25,69 @@ const Ops* get_ops(int type, int dtype, int g) {
 Batch::Batch(int type, int dtype, int lanes, const double* Q, const double* R, hipStream_t stream, std::mutex* owner_lock)
     : type_(type), dtype_(dtype), lanes_code_(lanes), owner_lock_(owner_lock), ops_(get_ops(type, dtype, lanes)), stream_(stream) {
   if (!ops_) throw std::runtime_error("target_estimation_amd: unsupported (model, precision, lanes-per-target) combination");
+  add_class(Q, R);
+}
+
+static std::string class_key(const double* Q, int nq, const double* R, int nr) {
+  std::string k((size_t)(nq + nr) * sizeof(double), '\0');
+  std::memcpy(&k[0], Q, (size_t)nq * sizeof(double));
+  std::memcpy(&k[(size_t)nq * sizeof(double)], R, (size_t)nr * sizeof(double));
+  return k;
+}
+
+int Batch::find_class(const double* Q, const double* R) const {
   const int n = ops_->L.n, m = ops_->L.m;
-  Q_.assign(Q, Q + n * n);
-  R_.assign(R, R + m * m);
+  auto it = class_index_.find(class_key(Q, n * n, R, m * m));
+  return it == class_index_.end() ? -1 : it->second;
+}
+
+int Batch::add_class(const double* Q, const double* R) {
+  const int n = ops_->L.n, m = ops_->L.m;
+  const int words = n * n + m * m;
   const size_t es = elem_size();
-  std::vector<unsigned char> host((size_t)(n * n + m * m) * es);
-  for (int i = 0; i < n * n + m * m; ++i) {
-    const double v = i < n * n ? Q_[i] : R_[i - n * n];
+  if (n_classes_ == qr_cap_) {   // grow the device table (geometric); recorded graphs hold the old pointer
+    const int want = qr_cap_ ? qr_cap_ * 2 : 1;
+    void* nt = nullptr;
+    TE_HIP_CHECK(hipMalloc(&nt, (size_t)want * words * es));
+    if (n_classes_ > 0) {
+      TE_HIP_CHECK(hipStreamSynchronize(stream_));
+      TE_HIP_CHECK(hipMemcpy(nt, d_qr_, (size_t)n_classes_ * words * es, hipMemcpyDeviceToDevice));
+    }
+    (void)hipFree(d_qr_);
+    d_qr_ = nt;
+    qr_cap_ = want;
+    drop_graphs();
+  }
+  std::vector<unsigned char> host((size_t)words * es);
+  for (int i = 0; i < words; ++i) {
+    const double v = i < n * n ? Q[i] : R[i - n * n];
     if (dtype_ == F64) reinterpret_cast<double*>(host.data())[i] = v;
     else reinterpret_cast<float*>(host.data())[i] = (float)v;
   }
-  TE_HIP_CHECK(hipMalloc(&d_qr_, host.size()));
-  TE_HIP_CHECK(hipMemcpy(d_qr_, host.data(), host.size(), hipMemcpyHostToDevice));
+  TE_HIP_CHECK(hipMemcpy(static_cast<char*>(d_qr_) + (size_t)n_classes_ * words * es, host.data(), host.size(), hipMemcpyHostToDevice));
+  class_index_.emplace(class_key(Q, n * n, R, m * m), n_classes_);
+  if (n_classes_ == 1) drop_graphs();   // the single-class kernels were recorded: from now on the per-class ones run
+  return n_classes_++;
+}
+
+StepParams Batch::base_params() const {
+  StepParams p;
+  p.rec = d_rec_; p.qr = d_qr_; p.cls = n_classes_ > 1 ? d_cls_ : nullptr; p.n = n_; p.idx = nullptr;
+  p.meas = nullptr; p.meas_ld = 0; p.has_meas = nullptr; p.dt_per = nullptr; p.dt = 0.0;
+  p.t_base = d_tbase_; p.nm_base = d_nmbase_;
+  return p;
 }
 
 Batch::~Batch() {
   (void)hipStreamSynchronize(stream_);
   drop_graphs();
   if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
-  (void)hipFree(d_qr_); (void)hipFree(d_rec_); (void)hipFree(d_tbase_); (void)hipFree(d_nmbase_);
+  (void)hipFree(d_qr_); (void)hipFree(d_rec_); (void)hipFree(d_tbase_); (void)hipFree(d_nmbase_); (void)hipFree(d_cls_);
   (void)hipFree(d_idx_); (void)hipFree(d_aos_); (void)hipFree(d_meas_); (void)hipFree(d_mask_); (void)hipFree(d_P0_);
   (void)hipFree(d_gate_ring_); (void)hipFree(d_gate_sum_); (void)hipFree(d_gate_state_); (void)hipFree(d_gate_prev_);
   (void)hipFree(d_dtper_);
   if (h_pin_) (void)hipHostFree(h_pin_);
   if (h_cache_) (void)hipHostFree(h_cache_);
-}
-
-bool Batch::same_params(int type, const double* Q, const double* R) const {
-  if (type != type_) return false;
-  return std::memcmp(Q, Q_.data(), Q_.size() * sizeof(double)) == 0 &&
-         std::memcmp(R, R_.data(), R_.size() * sizeof(double)) == 0;
 }
 
 void Batch::synchronize() {
@@ -89,20 +123,24 @@ void Batch::reserve(long n) {
   char* rec = nullptr;
   double* tb = nullptr;
   int* nm = nullptr;
+  int* cl = nullptr;
   TE_HIP_CHECK(hipMalloc((void**)&rec, new_bytes));
   TE_HIP_CHECK(hipMalloc((void**)&tb, sizeof(double) * want));
   TE_HIP_CHECK(hipMalloc((void**)&nm, sizeof(int) * want));
+  TE_HIP_CHECK(hipMalloc((void**)&cl, sizeof(int) * want));
   TE_HIP_CHECK(hipMemsetAsync(rec, 0, new_bytes, stream_));
   TE_HIP_CHECK(hipMemsetAsync(tb, 0, sizeof(double) * want, stream_));
   TE_HIP_CHECK(hipMemsetAsync(nm, 0, sizeof(int) * want, stream_));
+  TE_HIP_CHECK(hipMemsetAsync(cl, 0, sizeof(int) * want, stream_));
   if (cap_ > 0) {
     TE_HIP_CHECK(hipMemcpyAsync(rec, d_rec_, (size_t)(cap_ / tpw) * (size_t)ops_->L.tile_bytes, hipMemcpyDeviceToDevice, stream_));
     TE_HIP_CHECK(hipMemcpyAsync(tb, d_tbase_, sizeof(double) * cap_, hipMemcpyDeviceToDevice, stream_));
     TE_HIP_CHECK(hipMemcpyAsync(nm, d_nmbase_, sizeof(int) * cap_, hipMemcpyDeviceToDevice, stream_));
+    TE_HIP_CHECK(hipMemcpyAsync(cl, d_cls_, sizeof(int) * cap_, hipMemcpyDeviceToDevice, stream_));
   }
   TE_HIP_CHECK(hipStreamSynchronize(stream_));
-  (void)hipFree(d_rec_); (void)hipFree(d_tbase_); (void)hipFree(d_nmbase_);
-  d_rec_ = rec; d_tbase_ = tb; d_nmbase_ = nm; cap_ = want;
+  (void)hipFree(d_rec_); (void)hipFree(d_tbase_); (void)hipFree(d_nmbase_); (void)hipFree(d_cls_);
+  d_rec_ = rec; d_tbase_ = tb; d_nmbase_ = nm; d_cls_ = cl; cap_ = want;
   drop_graphs();
 }
 
@@ -124,13 +162,14 @@ void Batch::upload_slots(const int* slots, long n) {
 }
 
 long Batch::append(long count, const unsigned* ids, double t0, const double* P0, bool per_target_P0,
-                   const double* p0, const double* v0, const double* a0) {
+                   const double* p0, const double* v0, const double* a0, int cls, const int* cls_of, const int* P0_index,
+                   long P0_count) {
   touch();
   if (count <= 0) return n_;
   const long first = n_;
   const int N = ops_->L.n;
   reserve(n_ + count);
-  stage_reserve(count);
+  stage_reserve((cls_of || P0_index) ? 3 * count : count);   // slot list (+ per-entry class and P0 indices)
   std::vector<int> slots((size_t)count);
   for (long i = 0; i < count; ++i) slots[(size_t)i] = (int)(first + i);
   upload_slots(slots.data(), count);
@@ -140,7 +179,7 @@ long Batch::append(long count, const unsigned* ids, double t0, const double* P0,
   TE_HIP_CHECK(hipMemcpyAsync(d_p0, p0, sizeof(double) * 7 * count, hipMemcpyHostToDevice, stream_));
   if (v0) TE_HIP_CHECK(hipMemcpyAsync(d_v0, v0, sizeof(double) * 6 * count, hipMemcpyHostToDevice, stream_));
   if (a0) TE_HIP_CHECK(hipMemcpyAsync(d_a0, a0, sizeof(double) * 6 * count, hipMemcpyHostToDevice, stream_));
-  const long p0_words = (per_target_P0 ? count : 1) * (long)N * N;
+  const long p0_words = (P0_index ? P0_count : (per_target_P0 ? count : 1)) * (long)N * N;
   if (p0_words > P0_cap_) {
     TE_HIP_CHECK(hipStreamSynchronize(stream_));
     (void)hipFree(d_P0_);
@@ -151,6 +190,11 @@ long Batch::append(long count, const unsigned* ids, double t0, const double* P0,
   InitArgs a;
   a.rec = d_rec_; a.idx = d_idx_; a.n = count; a.p0 = d_p0; a.v0 = v0 ? d_v0 : nullptr; a.a0 = a0 ? d_a0 : nullptr;
   a.P0 = d_P0_; a.per_target_P0 = per_target_P0 ? 1 : 0;
+  a.cls = d_cls_; a.cls_value = cls;
+  if (cls_of || P0_index) {   // per-entry class / initial-covariance indices: behind the slot list in the index staging
+    if (cls_of) { TE_HIP_CHECK(hipMemcpyAsync(d_idx_ + count, cls_of, sizeof(int) * count, hipMemcpyHostToDevice, stream_)); a.cls_of = d_idx_ + count; }
+    if (P0_index) { TE_HIP_CHECK(hipMemcpyAsync(d_idx_ + 2 * count, P0_index, sizeof(int) * count, hipMemcpyHostToDevice, stream_)); a.P0_index = d_idx_ + 2 * count; }
+  }
   a.t_off = t0 - t_acc_; a.nm_off = (int)(-nm_acc_);
   a.t_base = d_tbase_; a.nm_base = d_nmbase_;
   ops_->init(a, stream_);
@@ -167,7 +211,7 @@ unsigned Batch::erase_slot(long slot) {
   const long last = n_ - 1;
   unsigned moved = slot_ids_[(size_t)slot];
   if (slot != last) {
-    ops_->move_record(d_rec_, last, slot, d_tbase_, d_nmbase_, stream_);
+    ops_->move_record(d_rec_, last, slot, d_tbase_, d_nmbase_, d_cls_, stream_);
     TE_HIP_CHECK(hipGetLastError());
     gate_move(last, slot);
     moved = slot_ids_[(size_t)last];
@@ -202,7 +246,7 @@ void Batch::erase_slots(const int* slots, long k, std::vector<std::pair<unsigned
     stage_reserve(2 * m);
     TE_HIP_CHECK(hipMemcpyAsync(d_idx_, src.data(), sizeof(int) * (size_t)m, hipMemcpyHostToDevice, stream_));
     TE_HIP_CHECK(hipMemcpyAsync(d_idx_ + m, dst.data(), sizeof(int) * (size_t)m, hipMemcpyHostToDevice, stream_));
-    ops_->move_records(d_rec_, d_idx_, d_idx_ + m, m, d_tbase_, d_nmbase_, stream_);
+    ops_->move_records(d_rec_, d_idx_, d_idx_ + m, m, d_tbase_, d_nmbase_, d_cls_, stream_);
     TE_HIP_CHECK(hipGetLastError());
     for (long j = 0; j < m; ++j) {
       gate_move(src[(size_t)j], dst[(size_t)j]);
@@ -219,9 +263,10 @@ void Batch::erase_slots(const int* slots, long k, std::vector<std::pair<unsigned
 void Batch::step_dense(double dt, const void* meas_dev, long ld, const unsigned char* has_dev) {
   touch();
   if (n_ == 0) return;
-  StepParams p;
-  p.rec = d_rec_; p.qr = d_qr_; p.n = n_; p.idx = nullptr; p.meas = meas_dev; p.meas_ld = ld;
-  p.has_meas = has_dev; p.dt_per = nullptr; p.dt = dt; p.t_base = d_tbase_; p.nm_base = d_nmbase_;
+  StepParams p = base_params();
+  p.meas = meas_dev; p.meas_ld = ld; p.has_meas = has_dev; p.dt = dt;
+  p.reverse = flip_ ? 1 : 0;   // zig-zag: consecutive dense ticks walk the tiles in opposite directions
+  flip_ = !flip_;
   ops_->step(p, stream_);
   t_acc_ += dt;
   if (meas_dev && !has_dev) nm_acc_ += 1;
@@ -239,17 +284,18 @@ void Batch::step_sequence(long n_ticks, double dt, const void* meas_base, long t
   const size_t es = elem_size();
   auto params = [&](long s0) {
     const long s = ring_ticks > 0 ? s0 % ring_ticks : s0;   // the measurements form a ring of ring_ticks ticks
-    StepParams p;
-    p.rec = d_rec_; p.qr = d_qr_; p.n = n_; p.idx = nullptr;
+    StepParams p = base_params();
     p.meas = meas_base ? static_cast<const char*>(meas_base) + (size_t)(s * tick_stride) * es : nullptr;
     p.meas_ld = ld;
     p.has_meas = has_base ? has_base + s * has_stride : nullptr;
-    p.dt_per = nullptr; p.dt = dt; p.t_base = d_tbase_; p.nm_base = d_nmbase_;
+    p.dt = dt;
+    p.reverse = (int)((s0 + (use_graph ? 0 : (flip_ ? 1 : 0))) & 1);   // zig-zag; a recorded graph starts forwards
     return p;
   };
   if (!use_graph) {
     for (long s = 0; s < n_ticks; ++s) ops_->step(params(s), stream_);
     TE_HIP_CHECK(hipGetLastError());
+    if (n_ticks & 1) flip_ = !flip_;
   } else {
     GraphEntry* hit = nullptr;
     for (auto& g : graphs_)
@@ -279,27 +325,30 @@ void Batch::step_sequence(long n_ticks, double dt, const void* meas_base, long t
     }
     if (use_graph == 2) return;  // record only
     TE_HIP_CHECK(hipGraphLaunch(hit->exec, stream_));
+    flip_ = (n_ticks & 1) != 0;   // the graph's last tick ran forwards (odd count) or backwards
   }
   t_acc_ += dt * (double)n_ticks;
   if (meas_base && !has_base) nm_acc_ += n_ticks;
 }
 
-void Batch::enqueue_tick(hipStream_t st, long s, double dt, const SeqSpec& q, bool query, const double* origin, double radius) {
+void Batch::enqueue_tick(hipStream_t st, long s, double dt, const SeqSpec& q, bool query, const double* origin, double radius,
+                         bool reverse) {
   if (n_ == 0) return;
   if (q.ring_ticks > 0) s %= q.ring_ticks;
   const size_t es = elem_size();
-  StepParams p;
-  p.rec = d_rec_; p.qr = d_qr_; p.n = n_; p.idx = nullptr;
+  const bool fused_q = ops_->fused_query && n_classes_ == 1;
+  StepParams p = base_params();
   p.meas = q.meas_base ? static_cast<const char*>(q.meas_base) + (size_t)(s * q.tick_stride) * es : nullptr;
   p.meas_ld = q.ld;
   p.has_meas = q.has_base ? q.has_base + s * q.has_stride : nullptr;
-  p.dt_per = nullptr; p.dt = dt; p.t_base = d_tbase_; p.nm_base = d_nmbase_;
-  if (query && ops_->fused_query) {
+  p.dt = dt;
+  p.reverse = reverse ? 1 : 0;
+  if (query && fused_q) {
     p.q_origin[0] = origin[0]; p.q_origin[1] = origin[1]; p.q_origin[2] = origin[2];
     p.q_radius = radius; p.q_delta = q.delta_dev; p.q_pose = q.pose_dev;
   }
   ops_->step(p, st);
-  if (query && !ops_->fused_query) {
+  if (query && !fused_q) {
     IntersectArgs a;
     a.rec = d_rec_; a.idx = nullptr; a.n = n_; a.t1 = std::numeric_limits<double>::quiet_NaN();
     a.origin[0] = origin[0]; a.origin[1] = origin[1]; a.origin[2] = origin[2]; a.radius = radius;
@@ -317,9 +366,8 @@ void Batch::step_fused(long n_ticks, double dt, const void* meas_base, long tick
                        const unsigned char* has_base, long has_stride) {
   touch();
   if (n_ == 0 || n_ticks <= 0) return;
-  StepParams p;
-  p.rec = d_rec_; p.qr = d_qr_; p.n = n_; p.idx = nullptr; p.meas = meas_base; p.meas_ld = ld;
-  p.has_meas = has_base; p.dt_per = nullptr; p.dt = dt; p.t_base = d_tbase_; p.nm_base = d_nmbase_;
+  StepParams p = base_params();
+  p.meas = meas_base; p.meas_ld = ld; p.has_meas = has_base; p.dt = dt;
   p.n_ticks = (int)n_ticks; p.tick_stride = tick_stride; p.has_stride = has_stride;
   ops_->step(p, stream_);
   TE_HIP_CHECK(hipGetLastError());
@@ -337,10 +385,9 @@ void Batch::step_indexed(const int* slots, long n, double dt, const double* meas
     ops_->pack_meas(d_aos_, n, d_meas_, n, stream_);
   }
   if (has) TE_HIP_CHECK(hipMemcpyAsync(d_mask_, has, (size_t)n, hipMemcpyHostToDevice, stream_));
-  StepParams p;
-  p.rec = d_rec_; p.qr = d_qr_; p.n = n; p.idx = d_idx_; p.meas = meas_aos ? d_meas_ : nullptr; p.meas_ld = n;
-  p.has_meas = (meas_aos && has) ? d_mask_ : nullptr; p.dt_per = nullptr; p.dt = dt;
-  p.t_base = d_tbase_; p.nm_base = d_nmbase_;
+  StepParams p = base_params();
+  p.n = n; p.idx = d_idx_; p.meas = meas_aos ? d_meas_ : nullptr; p.meas_ld = n;
+  p.has_meas = (meas_aos && has) ? d_mask_ : nullptr; p.dt = dt;
   ops_->step(p, stream_);
   TE_HIP_CHECK(hipGetLastError());
   TE_HIP_CHECK(hipStreamSynchronize(stream_));  // caller's host arrays may be reused after return
@@ -435,12 +482,11 @@ void Batch::flush() {
     pending_mark_[(size_t)p.slot] = 0;
   }
   pending_.clear();
-  StepParams p;
-  p.rec = d_rec_; p.qr = d_qr_; p.n = k; p.idx = reinterpret_cast<const int*>(d_pin_);
+  StepParams p = base_params();
+  p.n = k; p.idx = reinterpret_cast<const int*>(d_pin_);
   p.meas = any_has ? d_pin_ + off_meas : nullptr; p.meas_ld = k;
   p.has_meas = (any_has && !all_has) ? reinterpret_cast<const unsigned char*>(d_pin_ + off_has) : nullptr;
   p.dt_per = reinterpret_cast<const double*>(d_pin_ + off_dt); p.dt = 0.0;
-  p.t_base = d_tbase_; p.nm_base = d_nmbase_;
   ops_->step(p, stream_);
   if (cache_valid_) {   // keep the getter table current: only the stepped slots change
     OutArgs a;

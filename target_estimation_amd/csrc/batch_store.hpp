@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 
 #include <mutex>
+#include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -33,7 +35,12 @@ class Batch {
   const LayoutInfo& layout() const { return ops_->L; }
   long size() const { return n_; }
   size_t elem_size() const { return dtype_ == F64 ? 8 : 4; }
-  bool same_params(int type, const double* Q, const double* R) const;
+  // Parameter classes: the (Q, R) pairs of the batch's targets (TargetManager::init takes them per target,
+  // target_manager.hpp:85-87).  One class: Q, R are shared by every lane (scalar cache / LDS).  Several: a table in
+  // HBM plus one class index per slot, and the per-class kernels (PERQR) -- still one launch per tick.
+  int find_class(const double* Q, const double* R) const;   // -1: not there
+  int add_class(const double* Q, const double* R);
+  int n_classes() const { return n_classes_; }
   void set_stream(hipStream_t s) { stream_ = s; }
   hipStream_t stream() const { return stream_; }
   unsigned slot_id(long slot) const { return slot_ids_[slot]; }
@@ -41,8 +48,11 @@ class Batch {
   double clock() const { return t_acc_; }
 
   // Construct `count` new targets in slots [size(), size()+count).  Host arrays.
+  // cls: the class of every new target, or cls_of [count] one class each; P0_index [count] (with P0 = a table of
+  // P0_count matrices) gives every target the initial covariance of its row of the table.
   long append(long count, const unsigned* ids, double t0, const double* P0, bool per_target_P0,
-              const double* p0, const double* v0, const double* a0);
+              const double* p0, const double* v0, const double* a0, int cls = 0, const int* cls_of = nullptr,
+              const int* P0_index = nullptr, long P0_count = 0);
   // Remove a slot by moving the last slot into it; returns the id that now lives in `slot`
   // (or the erased id if it was the last one).
   unsigned erase_slot(long slot);
@@ -117,7 +127,8 @@ class Batch {
   };
   // tick s of the spec on `st`, without touching the batch clock.  With query: the own-time sphere
   // query of every slot runs inside the step kernel (one launch).
-  void enqueue_tick(hipStream_t st, long s, double dt, const SeqSpec& spec, bool query, const double* origin, double radius);
+  void enqueue_tick(hipStream_t st, long s, double dt, const SeqSpec& spec, bool query, const double* origin, double radius,
+                    bool reverse = false);
   void account_sequence(long n_ticks, double dt, bool all_measured);
   // identity of everything a recorded launch sequence refers to
   struct DevIdentity { const void* rec; const void* qr; const void* tbase; const void* nmbase; long n; };
@@ -145,8 +156,12 @@ class Batch {
   std::mutex* owner_lock_ = nullptr;
   const Ops* ops_;
   hipStream_t stream_;
-  std::vector<double> Q_, R_;
-  void* d_qr_ = nullptr;
+  std::unordered_map<std::string, int> class_index_;   // raw bytes of [Q | R] -> class
+  int n_classes_ = 0, qr_cap_ = 0;
+  void* d_qr_ = nullptr;           // [qr_cap_][N*N + K*K] in the batch precision
+  int* d_cls_ = nullptr;           // [cap_] class of every slot
+  bool flip_ = false;              // the next dense tick walks the tiles backwards (zig-zag, kf_step.hpp StepArgs::reverse)
+  StepParams base_params() const;
   char* d_rec_ = nullptr;
   double* d_tbase_ = nullptr;
   int* d_nmbase_ = nullptr;

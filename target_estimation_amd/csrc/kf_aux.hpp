@@ -55,8 +55,12 @@ struct InitArgs {
   const double* p0;        // [n][7]
   const double* v0;        // [n][6] or null
   const double* a0;        // [n][6] or null
-  const double* P0;        // [N*N] shared, or [n][N*N] when per_target_P0
+  const double* P0;        // [N*N] shared, [n][N*N] when per_target_P0, or a table indexed by P0_index
   int per_target_P0;
+  const int* P0_index = nullptr;   // [n]: entry e starts from P0 + P0_index[e] * N*N (per-class initial covariances)
+  int* cls = nullptr;              // per-slot parameter class array of the batch
+  const int* cls_of = nullptr;     // [n] class of entry e, or null: every entry gets cls_value
+  int cls_value = 0;
   double t_off;            // t0 - batch clock
   int nm_off;              // - batch measurement counter
   double* t_base;
@@ -98,7 +102,8 @@ __global__ void init_kernel(const InitArgs a) {
       for (int c = 0; c < 6; ++c) x0[12 + c] = a6[c];
     }
   }
-  const double* P0 = a.P0 + (a.per_target_P0 ? e * N * N : 0);
+  const double* P0 = a.P0 + (a.P0_index ? (long)a.P0_index[e] * N * N : (a.per_target_P0 ? e * N * N : 0));
+  if (a.cls) a.cls[slot] = a.cls_of ? a.cls_of[e] : a.cls_value;
   for (int r = 0; r < N; ++r) {
     state_set<C, T>(a.rec, slot, r, N, x0[r]);
     for (int c = ((C::PK || C::SEPPK) ? r : 0); c < N; ++c) state_set<C, T>(a.rec, slot, r, c, (T)P0[r * N + c]);
@@ -145,7 +150,7 @@ __global__ void set_state_kernel(char* rec, const int* idx, long n, const double
 
 // copy the whole record of slot `src` over slot `dst` (erase = swap-with-last compaction)
 template <class M, typename T, int G, int LAYOUT>
-__global__ void move_record_kernel(char* rec, long src, long dst, double* t_base, int* nm_base) {
+__global__ void move_record_kernel(char* rec, long src, long dst, double* t_base, int* nm_base, int* cls) {
   using C = Cfg<M, T, G, LAYOUT>;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= C::G * C::RW) return;
@@ -154,12 +159,12 @@ __global__ void move_record_kernel(char* rec, long src, long dst, double* t_base
                                     record_word_offset<C, T>((int)(src % C::TPW) * C::G + i, w));
   *reinterpret_cast<T*>(rec + (dst / C::TPW) * C::TILE_BYTES +
                         record_word_offset<C, T>((int)(dst % C::TPW) * C::G + i, w)) = v;
-  if (tid == 0) { t_base[dst] = t_base[src]; nm_base[dst] = nm_base[src]; }
+  if (tid == 0) { t_base[dst] = t_base[src]; nm_base[dst] = nm_base[src]; if (cls) cls[dst] = cls[src]; }
 }
 
 // m independent moves at once (batched erase: survivors from the tail fill the holes); blockIdx.y = move
 template <class M, typename T, int G, int LAYOUT>
-__global__ void move_records_kernel(char* rec, const int* src, const int* dst, long m, double* t_base, int* nm_base) {
+__global__ void move_records_kernel(char* rec, const int* src, const int* dst, long m, double* t_base, int* nm_base, int* cls) {
   using C = Cfg<M, T, G, LAYOUT>;
   const long mv = blockIdx.y;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -168,7 +173,7 @@ __global__ void move_records_kernel(char* rec, const int* src, const int* dst, l
   const int i = tid / C::RW, w = tid % C::RW;
   const T v = *reinterpret_cast<T*>(rec + (s / C::TPW) * C::TILE_BYTES + record_word_offset<C, T>((int)(s % C::TPW) * C::G + i, w));
   *reinterpret_cast<T*>(rec + (d / C::TPW) * C::TILE_BYTES + record_word_offset<C, T>((int)(d % C::TPW) * C::G + i, w)) = v;
-  if (tid == 0) { t_base[d] = t_base[s]; nm_base[d] = nm_base[s]; }
+  if (tid == 0) { t_base[d] = t_base[s]; nm_base[d] = nm_base[s]; if (cls) cls[d] = cls[s]; }
 }
 
 // measurements: AoS doubles [n][7] (the reference's Vector7d rows) -> SoA T [7][ld]

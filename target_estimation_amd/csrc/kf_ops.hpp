@@ -11,7 +11,8 @@ namespace te {
 
 struct StepParams {
   char* rec;
-  const void* qr;
+  const void* qr;                 // one [Q | R] block, or (cls != null) a table of them
+  const int* cls = nullptr;       // per-slot parameter class: selects the per-class kernels
   long n;
   const int* idx;                 // non-null selects the indexed kernel
   const void* meas;               // SoA [7][meas_ld] in the batch precision, or null (predict only)
@@ -29,6 +30,7 @@ struct StepParams {
   double q_radius = 0;
   double* q_delta = nullptr;
   double* q_pose = nullptr;
+  int reverse = 0;        // walk the tiles last-to-first (zig-zag between consecutive ticks: kf_step.hpp StepArgs)
 };
 
 struct Ops {
@@ -39,8 +41,8 @@ struct Ops {
   void (*init)(const InitArgs&, hipStream_t);
   void (*get_state)(char* rec, const int* idx, long n, double* x, double* P, hipStream_t);
   void (*set_state)(char* rec, const int* idx, long n, const double* x, const double* P, const double* uw, hipStream_t);
-  void (*move_record)(char* rec, long src, long dst, double* t_base, int* nm_base, hipStream_t);
-  void (*move_records)(char* rec, const int* src_dev, const int* dst_dev, long m, double* t_base, int* nm_base, hipStream_t);
+  void (*move_record)(char* rec, long src, long dst, double* t_base, int* nm_base, int* cls, hipStream_t);
+  void (*move_records)(char* rec, const int* src_dev, const int* dst_dev, long m, double* t_base, int* nm_base, int* cls, hipStream_t);
   void (*outputs)(const OutArgs&, hipStream_t);
   void (*pack_meas)(const double* aos, long n, void* soa, long ld, hipStream_t);
   void (*intersect)(const IntersectArgs&, hipStream_t);

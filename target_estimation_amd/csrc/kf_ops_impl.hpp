@@ -18,12 +18,13 @@ struct OpsImpl {
   static void step(const StepParams& p, hipStream_t s) {
     if (p.n <= 0) return;
     StepArgs<T> a;
-    a.rec = p.rec; a.qr = static_cast<const T*>(p.qr); a.n = p.n; a.idx = p.idx;
+    a.rec = p.rec; a.qr = static_cast<const T*>(p.qr); a.cls = p.cls; a.n = p.n; a.idx = p.idx;
     a.meas = static_cast<const T*>(p.meas); a.meas_ld = p.meas_ld; a.has_meas = p.has_meas;
     a.dt_per = p.dt_per; a.dt = p.dt; a.t_base = p.t_base; a.nm_base = p.nm_base;
     a.n_ticks = p.n_ticks; a.tick_stride = p.tick_stride; a.has_stride = p.has_stride;
     a.q_origin[0] = p.q_origin[0]; a.q_origin[1] = p.q_origin[1]; a.q_origin[2] = p.q_origin[2];
     a.q_radius = p.q_radius; a.q_delta = p.q_delta; a.q_pose = p.q_pose;
+    a.reverse = p.reverse;
     if (p.q_delta && (p.idx || p.n_ticks > 1))
       throw std::runtime_error("target_estimation_amd: the fused query needs a dense single-tick launch");
     const long waves = (p.n + C::TPW - 1) / C::TPW;
@@ -32,12 +33,18 @@ struct OpsImpl {
     const int wpb_dense = waves <= small_grid ? 1 : C::WPB;
     const unsigned blocks = (unsigned)((waves + wpb_dense - 1) / wpb_dense);
     if (p.n_ticks > 1 && p.idx) throw std::runtime_error("target_estimation_amd: fused multi-tick launches are dense only");
+    if (p.cls && (p.n_ticks > 1 || p.q_delta))
+      throw std::runtime_error("target_estimation_amd: a batch with several (Q, R) classes steps one tick per launch, without the fused query");
     if constexpr (C::SEP) {
       // small (latency-bound) grids: one wavefront per workgroup spreads the waves over more CUs
       const int wpb = waves <= small_grid ? 1 : 4;
       const unsigned b4 = (unsigned)((waves + wpb - 1) / wpb);
       const dim3 blk(64 * wpb);
-      if (p.n_ticks > 1)
+      if (p.cls && p.idx)
+        hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, true, false, false, true>), dim3(b4), blk, 0, s, a);
+      else if (p.cls)
+        hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, false, false, false, true>), dim3(b4), blk, 0, s, a);
+      else if (p.n_ticks > 1)
         hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, false, true>), dim3(b4), blk, 0, s, a);
       else if (p.idx)
         hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, true>), dim3(b4), blk, 0, s, a);
@@ -46,7 +53,11 @@ struct OpsImpl {
       else
         hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, false>), dim3(b4), blk, 0, s, a);
     } else {
-      if (p.n_ticks > 1)
+      if (p.cls && p.idx)
+        hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, true, false, false, true>), dim3(blocks), dim3(wpb_dense * 64), 0, s, a);
+      else if (p.cls)
+        hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, false, false, false, true>), dim3(blocks), dim3(wpb_dense * 64), 0, s, a);
+      else if (p.n_ticks > 1)
         hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, false, true>), dim3(blocks), dim3(wpb_dense * 64), 0, s, a);
       else if (p.idx)
         hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, true>), dim3(blocks), dim3(wpb_dense * 64), 0, s, a);
@@ -70,17 +81,17 @@ struct OpsImpl {
     const long th = n * C::N;
     hipLaunchKernelGGL((set_state_kernel<M, T, G, LAYOUT>), dim3((unsigned)((th + 255) / 256)), dim3(256), 0, s, rec, idx, n, x, P, uw);
   }
-  static void move_records(char* rec, const int* src, const int* dst, long m, double* t_base, int* nm_base, hipStream_t s) {
+  static void move_records(char* rec, const int* src, const int* dst, long m, double* t_base, int* nm_base, int* cls, hipStream_t s) {
     const int th = C::G * C::RW;
     for (long done = 0; done < m; done += 65535) {   // grid.y limit
       const long part = std::min<long>(65535, m - done);
       hipLaunchKernelGGL((move_records_kernel<M, T, G, LAYOUT>), dim3((th + 255) / 256, (unsigned)part), dim3(256), 0, s, rec, src + done,
-                         dst + done, part, t_base, nm_base);
+                         dst + done, part, t_base, nm_base, cls);
     }
   }
-  static void move_record(char* rec, long src, long dst, double* t_base, int* nm_base, hipStream_t s) {
+  static void move_record(char* rec, long src, long dst, double* t_base, int* nm_base, int* cls, hipStream_t s) {
     const int th = C::G * C::RW;
-    hipLaunchKernelGGL((move_record_kernel<M, T, G, LAYOUT>), dim3((th + 255) / 256), dim3(256), 0, s, rec, src, dst, t_base, nm_base);
+    hipLaunchKernelGGL((move_record_kernel<M, T, G, LAYOUT>), dim3((th + 255) / 256), dim3(256), 0, s, rec, src, dst, t_base, nm_base, cls);
   }
   static void outputs(const OutArgs& a, hipStream_t s) {
     if (a.n <= 0) return;

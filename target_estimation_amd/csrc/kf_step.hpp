@@ -32,7 +32,8 @@ namespace te {
 template <typename T>
 struct StepArgs {
   char* rec;                 // lane records, tile-major (te_layout.hpp)
-  const T* qr;               // Q (N*N row-major) then R (K*K row-major), compute precision
+  const T* qr;               // Q (N*N row-major) then R (K*K row-major), compute precision; PERQR: a table of such blocks
+  const int* cls;            // PERQR only: parameter class of slot s (its block of the qr table)
   long n;                    // dense: number of targets; indexed: number of entries
   const int* idx;            // indexed only: slot of entry e
   const T* meas;             // SoA [7][meas_ld]; row c = component c of [x y z qx qy qz qw]; may be null (predict only)
@@ -53,6 +54,11 @@ struct StepArgs {
   double q_radius;
   double* q_delta;
   double* q_pose;
+  // Zig-zag traversal: reverse != 0 walks the tiles from the last to the first.  Alternating the direction between
+  // consecutive ticks leaves the part of the state touched last in the 256 MB Infinity Cache for the start of the next
+  // tick (tools/zigzag_ceiling.hip: 480 MB of state in place 5.3 -> 6.6 TB/s, 960 MB 5.4 -> 6.0); results are
+  // independent of the order (targets are independent).
+  int reverse;
 };
 
 template <typename T> struct Vec16;
@@ -104,11 +110,14 @@ template <typename T> __device__ __forceinline__ T sel3(int c, T a, T b, T d) { 
 
 // QUERY: the own-time sphere query of the target runs after the store, on the posterior state (kf_aux.hpp,
 // sphere_query); with G > 1 the state is first collected from the G lanes through the wave's LDS scratch.
-template <class M, typename T, int G, int LAYOUT, bool INDEXED, bool FUSED = false, bool QUERY = false>
+// PERQR: every target reads the Q and R of its own parameter class (TargetManager::init takes Q, R per target,
+// target_manager.hpp:85-87) from a table in HBM (L2-resident for 10^3 classes) instead of the one pair staged in LDS.
+template <class M, typename T, int G, int LAYOUT, bool INDEXED, bool FUSED = false, bool QUERY = false, bool PERQR = false>
 __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kernel(const StepArgs<T> a) {
   using C = Cfg<M, T, G, LAYOUT>;
   constexpr bool PK = C::PK;
   static_assert(!(QUERY && (INDEXED || FUSED)), "the fused query is for dense single-tick launches");
+  static_assert(!(PERQR && (FUSED || QUERY)), "per-class Q/R: single-tick launches without the fused query");
   static_assert(!C::SEP, "the separable layout has its own kernel (kf_step_sep.hpp)");
   constexpr int N = C::N, K = C::K, RPL = C::RPL, KPL = C::KPL, TPW = C::TPW, GS = C::GS;
   constexpr int kStepWaves = C::WPB, kStepThreads = C::WPB * 64;
@@ -122,17 +131,22 @@ __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kern
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   // the launcher may use fewer wavefronts per workgroup than the LDS arrays are sized for (small grids)
-  const long wg = (long)blockIdx.x * (blockDim.x >> 6) + wave;  // wavefront-global index
+  long wg = (long)blockIdx.x * (blockDim.x >> 6) + wave;  // wavefront-global index
   if (wg * TPW >= a.n) return;                           // wave-uniform
+  if (a.reverse) wg = (a.n + TPW - 1) / TPW - 1 - wg;
   const int g = lane / G;
   const int i = (G == 1) ? 0 : lane % G;
   const long entry = wg * TPW + g;
-  const bool valid = (lane < C::LPT) && (entry < a.n);
+  bool valid = (lane < C::LPT) && (entry < a.n);
 
   long tile;
   int lt;  // lane inside the tile
+  long slot_of = entry;
   if constexpr (INDEXED) {
-    const long slot = valid ? (long)a.idx[entry] : 0;
+    long slot = valid ? (long)a.idx[entry] : -1;   // a negative slot = "skip this entry" (an id the device table did not resolve)
+    valid = slot >= 0;
+    if (!valid) slot = 0;
+    slot_of = slot;
     tile = slot / TPW;
     lt = (int)(slot % TPW) * G + i;
   } else {
@@ -140,6 +154,10 @@ __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kern
     lt = lane;
   }
   char* tb = a.rec + tile * C::TILE_BYTES;
+  const T* qr_own = a.qr;    // PERQR: this target's block of the table (per-lane vector loads)
+  if constexpr (PERQR) {
+    if (valid) qr_own = a.qr + (long)a.cls[slot_of] * C::QR_WORDS;
+  }
 
   // `mem` is the HBM image of the record, `rec` the full register image the step works on; they
   // are the same array unless the batch stores P symmetric-packed.
@@ -151,10 +169,12 @@ __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kern
     for (int w = 0; w < C::RW; ++w) mem[w] = 0;
   }
   T* sQw = s_qr + C::QR_WORDS * wave;
-  for (int e = lane; e < C::QR_WORDS; e += 64) sQw[e] = a.qr[e];
-  wave_lds_fence();
-  const T* sQ = sQw;
-  const T* sR = sQw + N * N;
+  if constexpr (!PERQR) {
+    for (int e = lane; e < C::QR_WORDS; e += 64) sQw[e] = a.qr[e];
+    wave_lds_fence();
+  }
+  const T* sQ = PERQR ? qr_own : sQw;
+  const T* sR = sQ + N * N;
   // per-wave LDS scratch: element `idx` of this lane's target at [idx*GS + g]
   T* sx = s_ex + (C::EX_WORDS > 0 ? C::EX_WORDS : 1) * wave;
 #define EXA_(idx) sx[(idx) * GS + g]
@@ -615,7 +635,7 @@ __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kern
     store_record<C, T>(tb, lt, mem);
     if (i == 0) {
       if constexpr (INDEXED) {
-        const long slot = a.idx[entry];
+        const long slot = slot_of;
         a.t_base[slot] += dtd * n_ticks;
         a.nm_base[slot] += n_has;
       } else {

@@ -78,23 +78,31 @@ __device__ __forceinline__ void sep_linear_axis(T* x, T (&P)[NB][NB], const T (&
 // QUERY: the own-time sphere-intersection query of the target (kf_aux.hpp, sphere_query) runs on the
 // posterior state while it is still in registers -- BASELINE.json configs[4], "per-step interception
 // point fused on-GPU": one launch per tick instead of step + query.
-template <class M, typename T, int LAYOUT, bool INDEXED, bool FUSED = false, bool QUERY = false>
+// PERQR: Q and R come from the target's own parameter class (a table in HBM, per-lane loads) instead of the one
+// shared pair read through the scalar cache.
+template <class M, typename T, int LAYOUT, bool INDEXED, bool FUSED = false, bool QUERY = false, bool PERQR = false>
 __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
   static_assert(!(QUERY && (INDEXED || FUSED)), "the fused query is for dense single-tick launches");
+  static_assert(!(PERQR && (FUSED || QUERY)), "per-class Q/R: single-tick launches without the fused query");
   using C = Cfg<M, T, 1, LAYOUT>;
   static_assert(C::SEP, "separable layouts only");
   constexpr int N = C::N, K = C::K, NB = C::NB, TPW = C::TPW;
   using F = Mth<T>;
 
   const int lane = threadIdx.x & 63;
-  const long wg = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  long wg = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (wg * TPW >= a.n) return;
+  if (a.reverse) wg = (a.n + TPW - 1) / TPW - 1 - wg;   // zig-zag traversal (StepArgs::reverse)
   const long entry = wg * TPW + lane;
-  const bool valid = entry < a.n;
+  bool valid = entry < a.n;
   long tile;
   int lt;
+  long slot_of = entry;
   if constexpr (INDEXED) {
-    const long slot = valid ? (long)a.idx[entry] : 0;
+    long slot = valid ? (long)a.idx[entry] : -1;   // a negative slot = "skip this entry"
+    valid = slot >= 0;
+    if (!valid) slot = 0;
+    slot_of = slot;
     tile = slot / TPW;
     lt = (int)(slot % TPW);
   } else {
@@ -115,7 +123,10 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
   }
   const T dt = (T)dtd;
   const T* Qm = a.qr;
-  const T* Rm = a.qr + N * N;
+  if constexpr (PERQR) {
+    if (valid) Qm = a.qr + (long)a.cls[slot_of] * C::QR_WORDS;
+  }
+  const T* Rm = Qm + N * N;
   // the [p v (a)] chains.  Linear models: K of them, rows {i, i+K, i+2K}.  EKF: x, y, z with rows
   // {i, i+6} (position, velocity), plus the 6-state attitude group (rows 3..5, 9..11).
   constexpr int NLIN = M::EKF ? 3 : K;
@@ -126,7 +137,7 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
   // once, here, behind the record loads, instead of chain by chain with a wait each (a serial chain of
   // scalar-cache round trips that a small, latency-bound batch feels directly).
   constexpr int QR_NEED = NLIN * LB * LB + NLIN + (M::EKF ? 36 + 9 : 0);
-  constexpr bool HOIST_QR = QR_NEED * (int)sizeof(T) <= 256;
+  constexpr bool HOIST_QR = !PERQR && QR_NEED * (int)sizeof(T) <= 256;
   T Qlin[HOIST_QR ? NLIN : 1][LB][LB], Rlin[HOIST_QR ? NLIN : 1], Qatt[HOIST_QR && M::EKF ? 6 : 1][6], Ratt[HOIST_QR && M::EKF ? 3 : 1][3];
   if constexpr (HOIST_QR) {
 #pragma unroll
@@ -411,7 +422,7 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
       sphere_query<M, T>(xq, true, 0.0, 0.0, a.q_origin, a.q_radius, &a.q_delta[entry], a.q_pose ? &a.q_pose[entry * 7] : nullptr);
     }
     if constexpr (INDEXED) {
-      const long slot = a.idx[entry];
+      const long slot = slot_of;
       a.t_base[slot] += dtd * n_ticks;
       a.nm_base[slot] += n_has;
     } else {

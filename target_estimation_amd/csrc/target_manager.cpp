@@ -139,10 +139,16 @@ int TargetManager::chooseLayout(int type, const double* Q, const double* R, cons
   return lanes_;
 }
 
-int TargetManager::findOrCreateBatch(int type, const double* Q, const double* R, int lanes_code) {
+int TargetManager::findOrCreateBatch(int type, const double* Q, const double* R, int lanes_code, int& cls) {
+  // a batch per (model, layout): at most a handful, so a scan; the (Q, R) class inside it is a hash lookup
   for (size_t b = 0; b < batches_.size(); ++b)
-    if (batches_[b]->same_params(type, Q, R) && batches_[b]->lanes_code() == lanes_code) return (int)b;
+    if (batches_[b]->type() == type && batches_[b]->lanes_code() == lanes_code) {
+      cls = batches_[b]->find_class(Q, R);
+      if (cls < 0) cls = batches_[b]->add_class(Q, R);
+      return (int)b;
+    }
   batches_.emplace_back(new Batch(type, dtype_, lanes_code, Q, R, stream_, &target_lock_));
+  cls = 0;
   return (int)batches_.size() - 1;
 }
 
@@ -209,8 +215,9 @@ void TargetManager::init(target_t type, unsigned id, double dt0, double t0, cons
   (void)dt0;  // only shapes the constructor's A, which every step rebuilds (uniform_velocity.cpp:40,67)
   lock_guard<mutex> lg(target_lock_);
   if (!targets_.contains(id)) {
-    const int b = findOrCreateBatch((int)type, Q, R, chooseLayout((int)type, Q, R, P0, 1));
-    const long slot = batches_[(size_t)b]->append(1, &id, t0, P0, false, p0, v0 ? v0 : kZero6, a0 ? a0 : kZero6);
+    int cls = 0;
+    const int b = findOrCreateBatch((int)type, Q, R, chooseLayout((int)type, Q, R, P0, 1), cls);
+    const long slot = batches_[(size_t)b]->append(1, &id, t0, P0, false, p0, v0 ? v0 : kZero6, a0 ? a0 : kZero6, cls);
     targets_.set(id, Loc{b, (int)slot});
     if (verbose_) {
       switch (type) {
@@ -261,10 +268,11 @@ long TargetManager::initBatch(target_t type, const unsigned* ids, long n, double
   }
   if (keep.empty()) return 0;
   const long k = (long)keep.size();
-  const int b = findOrCreateBatch((int)type, Q, R, chooseLayout((int)type, Q, R, P0, per_target_P0 ? n : 1));
+  int cls = 0;
+  const int b = findOrCreateBatch((int)type, Q, R, chooseLayout((int)type, Q, R, P0, per_target_P0 ? n : 1), cls);
   long first;
   if (k == n) {
-    first = batches_[(size_t)b]->append(n, ids, t0, P0, per_target_P0, p0, v0, a0);
+    first = batches_[(size_t)b]->append(n, ids, t0, P0, per_target_P0, p0, v0, a0, cls);
   } else {
     std::vector<unsigned> ids2((size_t)k);
     std::vector<double> p2((size_t)k * 7), v2, a2, P2;
@@ -280,11 +288,67 @@ long TargetManager::initBatch(target_t type, const unsigned* ids, long n, double
       if (per_target_P0) std::memcpy(&P2[(size_t)j * N * N], P0 + i * N * N, sizeof(double) * N * N);
     }
     first = batches_[(size_t)b]->append(k, ids2.data(), t0, per_target_P0 ? P2.data() : P0, per_target_P0, p2.data(),
-                                        v0 ? v2.data() : nullptr, a0 ? a2.data() : nullptr);
+                                        v0 ? v2.data() : nullptr, a0 ? a2.data() : nullptr, cls);
   }
   targets_.reserve(targets_.size() + (size_t)k);
   for (long j = 0; j < k; ++j) targets_.set(ids[keep[(size_t)j]], Loc{b, (int)(first + j)});
   return k;
+}
+
+long TargetManager::initBatchClasses(target_t type, const unsigned* ids, long n, double dt0, double t0, long n_classes,
+                                     const double* Q, const double* R, const double* P0, const unsigned* class_of,
+                                     const double* p0, const double* v0, const double* a0) {
+  (void)dt0;
+  lock_guard<mutex> lg(target_lock_);
+  if (n <= 0) return 0;
+  if (n_classes <= 0) throw std::invalid_argument("target_estimation_amd: initBatchClasses needs at least one class");
+  const int N = model_n((int)type), M = model_m((int)type);
+  // every class: its layout (the matrices decide) -> batch, and its index inside that batch
+  std::vector<int> cls_batch((size_t)n_classes), cls_idx((size_t)n_classes);
+  for (long c = 0; c < n_classes; ++c) {
+    const double* Qc = Q + c * N * N;
+    const double* Rc = R + c * M * M;
+    const double* Pc = P0 + c * N * N;
+    cls_batch[(size_t)c] = findOrCreateBatch((int)type, Qc, Rc, chooseLayout((int)type, Qc, Rc, Pc, 1), cls_idx[(size_t)c]);
+  }
+  // new ids only (existing ones are left untouched, as in init()), grouped by destination batch in input order
+  std::vector<std::vector<long>> rows(batches_.size());
+  {
+    IdTable seen;
+    seen.reserve((size_t)n);
+    for (long i = 0; i < n; ++i) {
+      if (class_of[i] >= (unsigned long)n_classes) throw std::invalid_argument("target_estimation_amd: class index out of range");
+      if (targets_.contains(ids[i]) || seen.contains(ids[i])) {
+        if (verbose_) std::cout << "Target(" << ids[i] << ") already exists!" << std::endl;
+        continue;
+      }
+      seen.set(ids[i], Loc{0, 0});
+      rows[(size_t)cls_batch[class_of[i]]].push_back(i);
+    }
+  }
+  long created = 0;
+  for (size_t b = 0; b < rows.size(); ++b) {
+    const long k = (long)rows[b].size();
+    if (!k) continue;
+    std::vector<unsigned> ids2((size_t)k);
+    std::vector<double> p2((size_t)k * 7), v2(v0 ? (size_t)k * 6 : 0), a2(a0 ? (size_t)k * 6 : 0);
+    std::vector<int> cls2((size_t)k), pidx((size_t)k);
+    for (long j = 0; j < k; ++j) {
+      const long i = rows[b][(size_t)j];
+      ids2[(size_t)j] = ids[i];
+      std::memcpy(&p2[(size_t)j * 7], p0 + i * 7, sizeof(double) * 7);
+      if (v0) std::memcpy(&v2[(size_t)j * 6], v0 + i * 6, sizeof(double) * 6);
+      if (a0) std::memcpy(&a2[(size_t)j * 6], a0 + i * 6, sizeof(double) * 6);
+      cls2[(size_t)j] = cls_idx[class_of[i]];
+      pidx[(size_t)j] = (int)class_of[i];
+    }
+    const long first = batches_[b]->append(k, ids2.data(), t0, P0, false, p2.data(), v0 ? v2.data() : nullptr,
+                                           a0 ? a2.data() : nullptr, 0, cls2.data(), pidx.data(), n_classes);
+    targets_.reserve(targets_.size() + (size_t)k);
+    for (long j = 0; j < k; ++j) targets_.set(ids2[(size_t)j], Loc{(int)b, (int)(first + j)});
+    created += k;
+  }
+  return created;
 }
 
 bool TargetManager::update(unsigned id, double dt, const double* meas) {
@@ -692,10 +756,16 @@ void TargetManager::stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpe
   const double zero3[3] = {0, 0, 0};
   const double* org = origin ? origin : zero3;
   if (!use_graph) {
-    for (long s = 0; s < n_ticks; ++s)
-      for (size_t b = 0; b < nb; ++b) {
-        batches_[b]->enqueue_tick(stream_, s, dt, specs[b], query, org, radius);
+    // Zig-zag over the WHOLE tick: tick s walks batch 0 .. nb-1, tiles forwards; tick s+1 walks batch nb-1 .. 0, tiles
+    // backwards, so that what the Infinity Cache still holds at the end of a tick is what the next tick reads first.
+    for (long s = 0; s < n_ticks; ++s) {
+      const bool rev = seq_flip_;
+      for (size_t k = 0; k < nb; ++k) {
+        const size_t b = rev ? nb - 1 - k : k;
+        batches_[b]->enqueue_tick(stream_, s, dt, specs[b], query, org, radius, rev);
       }
+      seq_flip_ = !seq_flip_;
+    }
     TE_HIP_CHECK(hipGetLastError());
   } else {
     auto same_spec = [](const Batch::SeqSpec& x, const Batch::SeqSpec& y) {
@@ -744,7 +814,7 @@ void TargetManager::stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpe
         for (size_t b = 0; b < nb; ++b) {
           if (batches_[b]->size() == 0) continue;
           set_deps(none);                                  // a new chain: no predecessor
-          for (long s = 0; s < n_ticks; ++s) batches_[b]->enqueue_tick(cap, s, dt, specs[b], query, org, radius);
+          for (long s = 0; s < n_ticks; ++s) batches_[b]->enqueue_tick(cap, s, dt, specs[b], query, org, radius, (s & 1) != 0);
           const Nodes tail = captured();
           leaves.insert(leaves.end(), tail.begin(), tail.end());
         }

@@ -83,6 +83,12 @@ class TargetManager {
   long initBatch(const unsigned* ids, long n, double dt0, double t0, const double* p0, const double* v0, const double* a0);
   long initBatch(target_t type, const unsigned* ids, long n, double dt0, double t0, const double* Q, const double* R,
                  const double* P0, bool per_target_P0, const double* p0, const double* v0, const double* a0);
+  // n targets whose (Q, R, P0) come from a table of n_classes parameter sets: class_of[i] is the row of target i
+  // (the reference's init takes Q, R, P0 per target, target_manager.hpp:85-87; a table + index is the same thing
+  // without n copies).  All classes of one layout share ONE batch, i.e. one launch per tick.
+  long initBatchClasses(target_t type, const unsigned* ids, long n, double dt0, double t0, long n_classes, const double* Q,
+                        const double* R, const double* P0, const unsigned* class_of, const double* p0, const double* v0,
+                        const double* a0);
   long updateBatch(const unsigned* ids, long n, double dt, const double* meas, const unsigned char* has_meas);
   // erase many targets in one call (one compaction launch per batch); unknown or repeated ids are reported
   // like erase() does and skipped; returns the number erased
@@ -133,7 +139,8 @@ class TargetManager {
   // lanes code of a new target's batch: the manager's explicit choice, or (auto) the axis-separable
   // layout when Q, R and every P0 allow it
   int chooseLayout(int type, const double* Q, const double* R, const double* P0, long n_P0) const;
-  int findOrCreateBatch(int type, const double* Q, const double* R, int lanes_code);
+  // the batch of (model, layout) -- created on first use -- and the parameter class of (Q, R) inside it
+  int findOrCreateBatch(int type, const double* Q, const double* R, int lanes_code, int& cls);
   bool find(unsigned id, Loc& loc);
 
   IdTable targets_;   // id -> (batch, slot); the reference's std::map<unsigned, TargetPtr> (target_manager.hpp:201)
@@ -158,6 +165,7 @@ class TargetManager {
   std::vector<hipStream_t> branch_streams_;   // [0]: the capture stream
   std::vector<hipEvent_t> branch_events_;
   void dropSeqGraphs();
+  bool seq_flip_ = false;   // zig-zag across the whole tick: the next eager all-batches tick runs last batch first, tiles backwards
 };
 
 }  // namespace te

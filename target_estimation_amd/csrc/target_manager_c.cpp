@@ -167,6 +167,21 @@ long target_manager_init_batch_typed(target_manager_c* self, int type, const uns
   return k;
 }
 
+long target_manager_init_batch_classes(target_manager_c* self, int type, const unsigned int* ids, long n, double dt0, double t0,
+                                       long n_classes, const double* Q, const double* R, const double* P0,
+                                       const unsigned int* class_of, const double* p0, const double* v0, const double* a0) {
+  long k = -1;
+  guarded("target_manager_init_batch_classes", [&] {
+    if (!ids || !Q || !R || !P0 || !class_of || !p0) throw std::invalid_argument("NULL argument");
+    k = M(self)->initBatchClasses((TargetManager::target_t)type, ids, n, dt0, t0, n_classes, Q, R, P0, class_of, p0, v0, a0);
+  });
+  return k;
+}
+
+int target_batch_num_classes(target_batch_c* b) {
+  return guarded_value<int>("target_batch_num_classes", -1, [&]() -> int { return B(b)->n_classes(); });
+}
+
 int target_manager_erase(target_manager_c* self, unsigned int id) {
   int r = -1;
   guarded("target_manager_erase", [&] { r = M(self)->erase(id) ? 1 : 0; });

@@ -54,6 +54,7 @@ class Batch:
     lanes_per_target = property(lambda s: s._lib.target_batch_lanes_per_target(s._h))
     symmetric_packed = property(lambda s: bool(s._lib.target_batch_is_symmetric_packed(s._h)))
     layout = property(lambda s: ("full", "symmetric_packed", "axis_separable", "axis_separable_packed")[s._lib.target_batch_layout(s._h)])
+    num_classes = property(lambda s: s._lib.target_batch_num_classes(s._h))
     algorithmic_bytes = property(lambda s: s._lib.target_batch_algorithmic_bytes(s._h))
     resident_bytes_per_target = property(lambda s: s._lib.target_batch_resident_bytes_per_target(s._h))
 
@@ -336,6 +337,22 @@ class TargetManager:
         return _check(self._lib.target_manager_init_batch_typed(
             self._h, int(type), idp, n, float(dt0), float(t0), _dp(Q), _dp(R), _dp(np.ascontiguousarray(P0)), per,
             _dp(p0), _dp(v0), _dp(a0)), "target_manager_init_batch_typed")
+
+    def init_batch_classes(self, ids, dt0, t0, p0, type, Q, R, P0, class_of, v0=None, a0=None):
+        """n targets with per-class parameters: Q [n_classes, ns, ns], R [n_classes, m, m], P0 [n_classes, ns, ns],
+        class_of [n] (the class of every target).  All classes of one layout share one batch (one launch per tick)."""
+        ids, idp = _ids(ids)
+        n = len(ids)
+        ns, m = MODEL_DIMS[int(type)]
+        Q, R, P0 = _d(Q), _d(R), _d(P0)
+        nc = Q.shape[0]
+        assert Q.shape == (nc, ns, ns) and R.shape == (nc, m, m) and P0.shape == (nc, ns, ns)
+        class_of = np.ascontiguousarray(class_of, dtype=np.uint32)
+        assert class_of.shape == (n,) and (class_of < nc).all()
+        p0, v0, a0 = _d(p0, (n, 7)), _d(v0, (n, 6)), _d(a0, (n, 6))
+        return _check(self._lib.target_manager_init_batch_classes(
+            self._h, int(type), idp, n, float(dt0), float(t0), nc, _dp(Q), _dp(R), _dp(P0), class_of.ctypes.data_as(capi.c_uint_p),
+            _dp(p0), _dp(v0), _dp(a0)), "target_manager_init_batch_classes")
 
     def update_batch(self, ids, dt, meas=None, has_meas=None):
         ids, idp = _ids(ids)
