@@ -52,7 +52,9 @@ SMALL = 200_000      # up to this many targets per GPU a tick is launch-bound: g
 RING_BYTES = 3 << 30  # cap of the measurement ring of a large workload
 RINGS = {"cfg2_stream": 2048, "cfg3_stream": 512}
 VARIANTS = {"ar1m_a90": dict(availability=0.9, rpy_noise=0.1), "av1m_a90": dict(availability=0.9, rpy_noise=0.1)}
-CLASSES = {"ar1m64_1kcls": 1000, "ar100k64_1kcls": 1000, "uv1m_1kcls": 1000}   # distinct (Q, R, P0) sets among the targets of ONE batch
+# distinct (Q, R, P0) sets among the targets of ONE batch; *_rand: every target draws its class at random (a wavefront's
+# 64 lanes then read 64 different table rows), otherwise targets of a class are neighbours (sorted class indices)
+CLASSES = {"ar1m64_1kcls": 1000, "ar1m64_1kcls_rand": 1000, "ar100k64_1kcls": 1000, "uv1m_1kcls": 1000}
 
 WORKLOADS = {
     # name: (description, model, dtype, targets per GPU, seed)
@@ -78,6 +80,7 @@ WORKLOADS = {
     "av8m": ("8000000 targets, angular-velocities model, fp32 (1.4 GB of state)", "angular_velocities", "f32", 8_000_000, 20240035),
     # per-target model parameters: 1000 distinct (Q, R, P0) classes in one batch (one launch per tick)
     "ar1m64_1kcls": ("1000000 targets, angular-rates model, fp64, 1000 distinct (Q, R, P0) classes in ONE batch", "angular_rates", "f64", 1_000_000, 20240041),
+    "ar1m64_1kcls_rand": ("1000000 targets, angular-rates model, fp64, 1000 distinct (Q, R, P0) classes in ONE batch, classes drawn at random per target", "angular_rates", "f64", 1_000_000, 20240041),
     "ar100k64_1kcls": ("100000 targets, angular-rates model, fp64, 1000 distinct (Q, R, P0) classes in ONE batch", "angular_rates", "f64", 100_000, 20240042),
     "uv1m_1kcls": ("1000000 targets, uniform-velocity model, fp64, 1000 distinct (Q, R, P0) classes in ONE batch", "uniform_velocity", "f64", 1_000_000, 20240043),
     # forced layouts
@@ -126,7 +129,7 @@ HEADLINE = "cfg4_1gpu"
 DEFAULT_EXTRA = ("cfg2,cfg2_stream,cfg3,cfg3_stream,cfg4,cfg4_64,cfg5,cfg4_1gpu32,cfg5_1gpu,cfg5_1gpu64,"
                  "uv1m,uv1m32,ua1m64,ua1m,av1m64,av1m,ar1m64,ar1m,"
                  "uv10m,ua10m,av4m64,ar4m64,av8m,ar8m,cfg4_4m,"
-                 "ar1m_a90,av1m_a90,ar1m64_1kcls,ar100k64_1kcls,uv1m_1kcls,uv1m_full,uv1m_packed,ar1m_full,ar1m_packed,av1m_packed,ar1m64_full,av1m64_full,ar1m64_packed,av1m64_packed")
+                 "ar1m_a90,av1m_a90,ar1m64_1kcls,ar1m64_1kcls_rand,ar100k64_1kcls,uv1m_1kcls,uv1m_full,uv1m_packed,ar1m_full,ar1m_packed,av1m_packed,ar1m64_full,av1m64_full,ar1m64_packed,av1m64_packed")
 DEFAULT_EXTRA_MULTI = "uv1m,ua1m64,av1m64,ar1m64,cfg4_64,cfg5,uv1m_strong,ar1m64_strong"
 
 
@@ -274,7 +277,7 @@ def run_workload(te, torch, name, steps, warmup, lanes=0, targets=None, dist=Non
         sc = rng.uniform(0.5, 2.0, (nc, 3))
         mgr.init_batch_classes(ids, dt, 0.0, st["p0"].cpu().numpy(), mtype, prm["Q"][None] * sc[:, 0, None, None],
                                prm["R"][None] * sc[:, 1, None, None], prm["P"][None] * sc[:, 2, None, None],
-                               rng.integers(0, nc, n_targets).astype(np.uint32))
+                               (rng.integers(0, nc, n_targets) if name.endswith("_rand") else np.sort(rng.integers(0, nc, n_targets))).astype(np.uint32))
         assert len(mgr.batches()) == 1 and mgr.batches()[0].num_classes == nc
     else:
         mgr.init_batch(ids, dt, 0.0, st["p0"].cpu().numpy())
@@ -578,6 +581,49 @@ def parity_report(te, torch, parts, dtype, seed, n_sample=256, checkpoints=(1, 1
     return rep
 
 
+def gather_report(te, torch, dist, rank, world, workload="ar1m64", ticks=16):
+    """The library's RCCL pose gather (target_manager_gather_pose_*: direct sends to rank 0 on a second stream behind an
+    event).  Exposed = begin + wait with nothing else running; overlapped = begin, then `ticks` ticks, then wait: what
+    the ticks cost on top of their own time is what the gather did NOT hide."""
+    from target_estimation_amd.dist import PoseGather
+    r = run_workload(te, torch, workload, ticks, 4, dist=dist, rank=rank, world=world, reps=2, keep=True)
+    mgr, b, meas, ids, dt = r.pop("_mgr")
+    g = PoseGather(mgr)
+    counts = g.counts()
+    clock = Clock(torch, dist)
+
+    def timed(fn):
+        clock.fence()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3
+
+    def only_gather():
+        g.begin(counts)
+        g.wait()
+
+    def only_ticks():
+        b.step_sequence(dt, meas, None, use_graph=False, n_ticks=ticks)
+
+    def both():
+        g.begin(counts)
+        b.step_sequence(dt, meas, None, use_graph=False, n_ticks=ticks)
+        g.wait()
+
+    only_gather(); only_ticks()
+    exposed = min(timed(only_gather) for _ in range(5))
+    t_ticks = min(timed(only_ticks) for _ in range(5))
+    t_both = min(timed(both) for _ in range(5))
+    out = dict(name="gather_pose", workload=workload, n_gpus=world, rows_per_rank=counts[0], rows_total=sum(counts),
+               bytes_to_root=sum(counts) * 56, gather_pose_ms_exposed=exposed, ticks=ticks, ticks_ms=t_ticks,
+               ticks_plus_gather_ms=t_both, gather_pose_ms_overlapped=max(0.0, t_both - t_ticks),
+               transport="RCCL ncclSend/ncclRecv to rank 0 on a second stream" if world > 1 else "world size 1: the root's own rows only (no peer traffic)")
+    g.close()
+    mgr.close()
+    return out
+
+
 def copy_bandwidth(torch, nbytes=1 << 30, reps=10):
     """Streaming rates of this box in GB/s (bytes read + bytes written per second), the practical HBM ceilings SURVEY 8d
     asks to record next to the 8 TB/s spec peak: a device-to-device copy (dst.copy_(src): 1 read + 1 write) and a triad
@@ -685,6 +731,7 @@ def main():
     ap.add_argument("--gather", action="store_true",
                     help="N > 1: every K ticks gather all ranks' pose7 rows to rank 0 through the library's RCCL gather on a second "
                          "stream, overlapped with the next ticks; reports gather_pose_ms overlapped vs exposed")
+    ap.add_argument("--no-gather", action="store_true", help="skip the gather report (N = 1 runs it on a one-rank communicator)")
     ap.add_argument("--launch-mode", default="auto", choices=["auto", "python", "sequence", "graph", "fused"],
                     help="how the per-tick launches are enqueued (always one kernel launch per batch per tick, except 'fused')")
     ap.add_argument("--dry-run", action="store_true", help="no device work: rank start-up, rendezvous, barriers, timing protocol and "
@@ -803,13 +850,21 @@ def main():
                       | {"roofline_frac": r["achieved_gbs"] / HBM_PEAK_GBS, "n_gpus": world,
                          "traffic_per_step": (sum(tr) if all(t is not None for t in tr) else None)})
         torch.cuda.empty_cache()
+    if (args.gather or world == 1) and not args.no_gather:
+        try:
+            gr = gather_report(te, torch, dist, rank, world)
+            extras.append(gr)
+            out["config"]["gather_pose_ms"] = {"exposed": gr["gather_pose_ms_exposed"], "overlapped": gr["gather_pose_ms_overlapped"],
+                                               "rows_total": gr["rows_total"], "ticks_overlapped_with": gr["ticks"]}
+        except Exception as exc:
+            extras.append({"name": "gather_pose", "error": str(exc)[:300]})
     if extras:
         out["extra"] = extras
         # the HBM-bound rows (state > 1 GB) also go into `roofline`, where a reader of the top-level keys finds them
         out["roofline"]["hbm_bound"] = {e["name"]: {"achieved": e["achieved_gbs"], "frac": e["roofline_frac"], "cycles_per_s": e["cycles_per_s"]}
-                                        for e in extras if "error" not in e and e["residency"].startswith("HBM-bound")}
+                                        for e in extras if "error" not in e and e.get("residency", "").startswith("HBM-bound")}
         out["roofline"]["l3_assisted"] = {e["name"]: {"achieved": e["achieved_gbs"], "frac": e["roofline_frac"], "cycles_per_s": e["cycles_per_s"]}
-                                          for e in extras if "error" not in e and e["residency"].startswith("L3-assisted")}
+                                          for e in extras if "error" not in e and e.get("residency", "").startswith("L3-assisted")}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

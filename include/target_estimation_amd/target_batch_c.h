@@ -234,6 +234,26 @@ int target_batch_gate_update_dev(target_batch_c* b, const double* delta_dev, con
 /* AoS doubles [n][7] (host layout of the reference) -> SoA [7][ld] in the batch precision, on device */
 int target_batch_pack_meas_dev(target_batch_c* b, const double* meas_aos_dev, long n, void* meas_soa_dev, long ld);
 
+/* ---- multi-GPU: gather of the estimated poses to one rank over xGMI (RCCL) ---------------------------- */
+/* One process per GPU, every rank owns a shard of the targets (no collective in the predict/update path).  What the
+ * reference's node does with the filtered poses every tick is publish them (src/target_manager_ros.cpp:78-87); across
+ * GPUs that is a gather of pose7 rows to one rank.  It is a direct gather (one ncclSend per rank, one ncclRecv per peer
+ * on the root: xGMI is point-to-point) on the communicator's own stream behind an event, so the step kernels of the
+ * following ticks run while the poses travel.
+ *   target_comm_unique_id : rank 0 creates the 128-byte id; the caller hands it to every rank (any channel)
+ *   target_comm_new       : ncclCommInitRank on the calling thread's current HIP device (collective over all ranks)
+ *   ..._gather_pose_begin : enqueue.  counts [world] = rows per rank (counts[rank] == target_manager_size);
+ *                           recv_dev (root only) [sum(counts)][7] doubles, rank r's rows at row sum(counts[:r]), batch
+ *                           order then slot order within a rank.  Returns immediately.
+ *   ..._gather_pose_wait  : block the host until the last gather has finished; device_ms (may be NULL) = its duration
+ * RCCL is looked up at run time (the copy already in the process, else librccl.so.1). */
+typedef void target_comm_c;
+int target_comm_unique_id(char* out128);
+target_comm_c* target_comm_new(const char* id128, int rank, int world);
+void target_comm_delete(target_comm_c* comm);
+int target_manager_gather_pose_begin(target_manager_c* self, target_comm_c* comm, int root, const long* counts, double* recv_dev);
+int target_manager_gather_pose_wait(target_comm_c* comm, float* device_ms);
+
 /* ---- measurement ingest: the ROS node's mailbox / has-measurement / expiry policy --------------- */
 /* Transport-agnostic restatement of class Measurement (target_manager_ros.hpp:74-134) and
  * RosTargetManager::update (src/target_manager_ros.cpp:41-92).  The caller pushes (id | frame name,

@@ -72,6 +72,11 @@ SIGNATURES = {
                                                               C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "target_batch_gate_update_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "target_batch_intersect_sphere_dev": (C.c_int, [C.c_void_p, C.c_double, c_double_p, C.c_double, C.c_void_p, C.c_void_p]),
+    "target_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "target_comm_new": (C.c_void_p, [C.c_char_p, C.c_int, C.c_int]),
+    "target_comm_delete": (None, [C.c_void_p]),
+    "target_manager_gather_pose_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_long), C.c_void_p]),
+    "target_manager_gather_pose_wait": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "target_ingest_new": (C.c_void_p, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p]),
     "target_ingest_delete": (None, [C.c_void_p]),
     "target_ingest_set_expiration_time": (None, [C.c_void_p, C.c_double]),

@@ -2,6 +2,7 @@
 #include "batch_store.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <stdexcept>
@@ -43,7 +44,8 @@ int Batch::find_class(const double* Q, const double* R) const {
 
 int Batch::add_class(const double* Q, const double* R) {
   const int n = ops_->L.n, m = ops_->L.m;
-  const int words = n * n + m * m;
+  const bool sep = ops_->L.layout == LAYOUT_SEPARABLE || ops_->L.layout == LAYOUT_SEPARABLE_PACKED;
+  const int words = qr_words(type_, sep);   // te_layout.hpp: full [Q | R], or only the in-group entries (separable layouts)
   const size_t es = elem_size();
   if (n_classes_ == qr_cap_) {   // grow the device table (geometric); recorded graphs hold the old pointer
     const int want = qr_cap_ ? qr_cap_ * 2 : 1;
@@ -59,11 +61,15 @@ int Batch::add_class(const double* Q, const double* R) {
     drop_graphs();
   }
   std::vector<unsigned char> host((size_t)words * es);
-  for (int i = 0; i < words; ++i) {
-    const double v = i < n * n ? Q[i] : R[i - n * n];
-    if (dtype_ == F64) reinterpret_cast<double*>(host.data())[i] = v;
-    else reinterpret_cast<float*>(host.data())[i] = (float)v;
-  }
+  auto put = [&](int w, double v) {
+    if (w < 0) return;   // an entry between different axis groups: zero by the separable layout's precondition
+    if (dtype_ == F64) reinterpret_cast<double*>(host.data())[w] = v;
+    else reinterpret_cast<float*>(host.data())[w] = (float)v;
+  };
+  for (int r = 0; r < n; ++r)
+    for (int c = 0; c < n; ++c) put(qr_q_word(type_, sep, r, c), Q[r * n + c]);
+  for (int r = 0; r < m; ++r)
+    for (int c = 0; c < m; ++c) put(qr_r_word(type_, sep, r, c), R[r * m + c]);
   TE_HIP_CHECK(hipMemcpy(static_cast<char*>(d_qr_) + (size_t)n_classes_ * words * es, host.data(), host.size(), hipMemcpyHostToDevice));
   class_index_.emplace(class_key(Q, n * n, R, m * m), n_classes_);
   if (n_classes_ == 1) drop_graphs();   // the single-class kernels were recorded: from now on the per-class ones run
@@ -88,6 +94,11 @@ Batch::~Batch() {
   (void)hipFree(d_dtper_);
   if (h_pin_) (void)hipHostFree(h_pin_);
   if (h_cache_) (void)hipHostFree(h_cache_);
+}
+
+long Batch::zigzag_min_bytes() {
+  static const long v = [] { const char* e = std::getenv("TE_ZIGZAG_MIN_MB"); return (e ? std::atol(e) : 128L) << 20; }();
+  return v;
 }
 
 void Batch::synchronize() {
@@ -265,7 +276,7 @@ void Batch::step_dense(double dt, const void* meas_dev, long ld, const unsigned 
   if (n_ == 0) return;
   StepParams p = base_params();
   p.meas = meas_dev; p.meas_ld = ld; p.has_meas = has_dev; p.dt = dt;
-  p.reverse = flip_ ? 1 : 0;   // zig-zag: consecutive dense ticks walk the tiles in opposite directions
+  p.reverse = (flip_ && zigzag()) ? 1 : 0;   // zig-zag: consecutive dense ticks walk the tiles in opposite directions
   flip_ = !flip_;
   ops_->step(p, stream_);
   t_acc_ += dt;
@@ -289,7 +300,7 @@ void Batch::step_sequence(long n_ticks, double dt, const void* meas_base, long t
     p.meas_ld = ld;
     p.has_meas = has_base ? has_base + s * has_stride : nullptr;
     p.dt = dt;
-    p.reverse = (int)((s0 + (use_graph ? 0 : (flip_ ? 1 : 0))) & 1);   // zig-zag; a recorded graph starts forwards
+    p.reverse = zigzag() ? (int)((s0 + (use_graph ? 0 : (flip_ ? 1 : 0))) & 1) : 0;   // zig-zag; a recorded graph starts forwards
     return p;
   };
   if (!use_graph) {
@@ -391,6 +402,26 @@ void Batch::step_indexed(const int* slots, long n, double dt, const double* meas
   ops_->step(p, stream_);
   TE_HIP_CHECK(hipGetLastError());
   TE_HIP_CHECK(hipStreamSynchronize(stream_));  // caller's host arrays may be reused after return
+}
+
+void Batch::step_indexed_dev(const int* idx_dev, long n, double dt, const void* meas_soa_dev, long ld, const unsigned char* has_dev) {
+  touch();
+  if (n <= 0) return;
+  StepParams p = base_params();
+  p.n = n; p.idx = idx_dev; p.meas = meas_soa_dev; p.meas_ld = ld;
+  p.has_meas = meas_soa_dev ? has_dev : nullptr; p.dt = dt;
+  ops_->step(p, stream_);
+  TE_HIP_CHECK(hipGetLastError());
+}
+
+void Batch::outputs_indexed_dev(const int* idx_dev, long n, double* pose_dev, double* twist_dev, double* acc_dev, bool at_time, double t1) {
+  flush();
+  if (n <= 0) return;
+  OutArgs a;
+  a.rec = d_rec_; a.idx = idx_dev; a.n = n; a.pose = pose_dev; a.twist = twist_dev; a.acc = acc_dev;
+  a.at_time = at_time ? 1 : 0; a.t1 = t1; a.t_acc = t_acc_; a.t_base = d_tbase_;
+  ops_->outputs(a, stream_);
+  TE_HIP_CHECK(hipGetLastError());
 }
 
 void Batch::step_dense_host(double dt, const double* meas_aos, const unsigned char* has) {

@@ -77,6 +77,11 @@ class Batch {
                   const unsigned char* has_base, long has_stride);
   // One tick over the listed slots, host inputs (meas rows follow the order of `slots`).
   void step_indexed(const int* slots, long n, double dt, const double* meas_aos, const unsigned char* has);
+  // The same with everything already on the device: idx_dev [n] = slot of entry e or a negative number (entry skipped);
+  // meas_soa_dev SoA [7][ld] in the batch precision, rows in entry order.  Asynchronous.
+  void step_indexed_dev(const int* idx_dev, long n, double dt, const void* meas_soa_dev, long ld, const unsigned char* has_dev);
+  // derived outputs of the listed entries into device arrays (row e; entries with a negative slot are left untouched)
+  void outputs_indexed_dev(const int* idx_dev, long n, double* pose_dev, double* twist_dev, double* acc_dev, bool at_time, double t1);
   // One-target call of the reference's C ABI (target_manager_update / update_meas).  The step is
   // QUEUED: it runs, together with every other queued one-target step, as a single indexed launch
   // when anything reads or otherwise touches the batch (flush()).  A slot queued twice flushes first,
@@ -145,6 +150,8 @@ class Batch {
   // bytes of HBM one predict+update cycle must move for one target (state read+write + the
   // measurement words the model reads); used by the roofline accounting
   long algorithmic_bytes_per_cycle() const;
+  long state_bytes() const { return (n_ + ops_->L.tpw - 1) / ops_->L.tpw * ops_->L.tile_bytes; }
+  static long zigzag_min_bytes();   // default 128 MB (env TE_ZIGZAG_MIN_MB)
   char* records_dev() const { return d_rec_; }
 
  private:
@@ -161,6 +168,9 @@ class Batch {
   void* d_qr_ = nullptr;           // [qr_cap_][N*N + K*K] in the batch precision
   int* d_cls_ = nullptr;           // [cap_] class of every slot
   bool flip_ = false;              // the next dense tick walks the tiles backwards (zig-zag, kf_step.hpp StepArgs::reverse)
+  // Zig-zag only pays when the state does not fit the Infinity Cache, and it costs when the state is L2-resident: a tile
+  // walked backwards lands on another XCD, whose L2 does not hold it (10^5 UA fp32: 4.7 -> 8.2 us per tick).
+  bool zigzag() const { return state_bytes() >= zigzag_min_bytes(); }
   StepParams base_params() const;
   char* d_rec_ = nullptr;
   double* d_tbase_ = nullptr;

@@ -282,6 +282,7 @@ __global__ void outputs_kernel(const OutArgs a) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= a.n) return;
   const long slot = a.idx ? (long)a.idx[e] : e;
+  if (slot < 0) return;   // an entry that is not in this batch (device-resolved ids, id_resolve.hpp)
   T x[N];
 #pragma unroll
   for (int r = 0; r < N; ++r) x[r] = state_get<C, T>(a.rec, slot, r, N);

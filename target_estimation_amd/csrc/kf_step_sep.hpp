@@ -126,7 +126,6 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
   if constexpr (PERQR) {
     if (valid) Qm = a.qr + (long)a.cls[slot_of] * C::QR_WORDS;
   }
-  const T* Rm = Qm + N * N;
   // the [p v (a)] chains.  Linear models: K of them, rows {i, i+K, i+2K}.  EKF: x, y, z with rows
   // {i, i+6} (position, velocity), plus the 6-state attitude group (rows 3..5, 9..11).
   constexpr int NLIN = M::EKF ? 3 : K;
@@ -145,18 +144,18 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
 #pragma unroll
       for (int b = 0; b < LB; ++b)
 #pragma unroll
-        for (int c = 0; c < LB; ++c) Qlin[i][b][c] = Qm[(i + STRIDE * b) * N + (i + STRIDE * c)];
-      Rlin[i] = Rm[i * K + i];
+        for (int c = 0; c < LB; ++c) Qlin[i][b][c] = Qm[C::QWORD.v[i + STRIDE * b][i + STRIDE * c]];
+      Rlin[i] = Qm[C::RWORD.v[i][i]];
     }
     if constexpr (M::EKF) {
 #pragma unroll
       for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int c = 0; c < 6; ++c) Qatt[r][c] = Qm[GRA[r] * N + GRA[c]];
+        for (int c = 0; c < 6; ++c) Qatt[r][c] = Qm[C::QWORD.v[GRA[r]][GRA[c]]];
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) Ratt[r][c] = Rm[(3 + r) * K + (3 + c)];
+        for (int c = 0; c < 3; ++c) Ratt[r][c] = Qm[C::RWORD.v[3 + r][3 + c]];
     }
   }
   int n_has = 0;
@@ -230,7 +229,7 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
       for (int c = 0; c < LB; ++c) {
         Pb[b][c] = mem[C::PWORD.v[i + STRIDE * b][i + STRIDE * c]];
         if constexpr (HOIST_QR) Qb[b][c] = Qlin[i][b][c];
-        else Qb[b][c] = Qm[(i + STRIDE * b) * N + (i + STRIDE * c)];
+        else Qb[b][c] = Qm[C::QWORD.v[i + STRIDE * b][i + STRIDE * c]];
       }
     }
     T y = 0;
@@ -244,7 +243,7 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
     }
     T r_meas;
     if constexpr (HOIST_QR) r_meas = Rlin[i];
-    else r_meas = Rm[i * K + i];
+    else r_meas = Qm[C::RWORD.v[i][i]];
     sep_linear_axis<LB, T>(xs, Pb, Qb, r_meas, dt, has, y);
 #pragma unroll
     for (int b = 0; b < LB; ++b) {
@@ -336,7 +335,7 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
       for (int c = 0; c < 6; ++c) {
         T qrc;
         if constexpr (HOIST_QR) qrc = Qatt[r][c];
-        else qrc = Qm[GR[r] * N + GR[c]];
+        else qrc = Qm[C::QWORD.v[GR[r]][GR[c]]];
         Pr[r][c] = (c < 3 ? nw[c < 3 ? c : 0] : Pr[r][c]) + qrc;
       }
     }
@@ -348,7 +347,7 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
         for (int c = 0; c < 3; ++c) {
           T rrc;
           if constexpr (HOIST_QR) rrc = Ratt[r][c];
-          else rrc = Rm[(3 + r) * K + (3 + c)];
+          else rrc = Qm[C::RWORD.v[3 + r][3 + c]];
           S[r][c] = Pr[r][c] + rrc;
         }
 #pragma unroll

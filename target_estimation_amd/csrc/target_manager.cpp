@@ -1,6 +1,7 @@
 // target_manager.cpp -- see target_manager.hpp.
 #include "target_manager.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -35,7 +36,90 @@ TargetManager::TargetManager(const std::string& file, int dtype, int lanes_per_t
     default_values_loaded_ = true;
 }
 
+void TargetManager::devIdsFree() {
+  DevIds& d = dev_ids_;
+  (void)hipFree(d.keys); (void)hipFree(d.vals); (void)hipFree(d.seen);
+  (void)hipFree(d.ids); (void)hipFree(d.loc); (void)hipFree(d.idx); (void)hipFree(d.aos); (void)hipFree(d.soa);
+  (void)hipFree(d.mask); (void)hipFree(d.found); (void)hipFree(d.out); (void)hipFree(d.counters);
+  if (d.h_counters) (void)hipHostFree(d.h_counters);
+  d = DevIds();
+}
+
+void TargetManager::devIdsReserve(long n) {
+  DevIds& d = dev_ids_;
+  if (!d.counters) {
+    TE_HIP_CHECK(hipMalloc((void**)&d.counters, sizeof(ResolveCounters)));
+    TE_HIP_CHECK(hipHostMalloc((void**)&d.h_counters, sizeof(ResolveCounters), hipHostMallocDefault));
+  }
+  if (n <= d.cap) return;
+  const long want = std::max(n, d.cap * 2);
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));
+  (void)hipFree(d.ids); (void)hipFree(d.loc); (void)hipFree(d.idx); (void)hipFree(d.aos); (void)hipFree(d.soa);
+  (void)hipFree(d.mask); (void)hipFree(d.found); (void)hipFree(d.out);
+  TE_HIP_CHECK(hipMalloc((void**)&d.ids, sizeof(unsigned) * want));
+  TE_HIP_CHECK(hipMalloc((void**)&d.loc, sizeof(int) * want));
+  TE_HIP_CHECK(hipMalloc((void**)&d.idx, sizeof(int) * want));
+  TE_HIP_CHECK(hipMalloc((void**)&d.aos, sizeof(double) * 7 * want));
+  TE_HIP_CHECK(hipMalloc((void**)&d.soa, (dtype_ == F64 ? 8 : 4) * 7 * (size_t)want));
+  TE_HIP_CHECK(hipMalloc((void**)&d.mask, (size_t)want));
+  TE_HIP_CHECK(hipMalloc((void**)&d.found, (size_t)want));
+  TE_HIP_CHECK(hipMalloc((void**)&d.out, sizeof(double) * 19 * want));
+  d.cap = want;
+}
+
+void TargetManager::devIdsRebuild() {
+  DevIds& d = dev_ids_;
+  const size_t total = targets_.size();
+  int log2cap = 4;
+  while ((size_t(1) << log2cap) < 2 * total + 16) ++log2cap;
+  if (log2cap > 31) throw std::runtime_error("target_estimation_amd: too many targets for the device id table");
+  if (log2cap != d.log2cap) {
+    TE_HIP_CHECK(hipStreamSynchronize(stream_));
+    (void)hipFree(d.keys); (void)hipFree(d.vals); (void)hipFree(d.seen);
+    const size_t cap = size_t(1) << log2cap;
+    TE_HIP_CHECK(hipMalloc((void**)&d.keys, sizeof(unsigned) * cap));
+    TE_HIP_CHECK(hipMalloc((void**)&d.vals, sizeof(unsigned) * cap));
+    TE_HIP_CHECK(hipMalloc((void**)&d.seen, sizeof(int) * cap));
+    d.log2cap = log2cap;
+  }
+  const size_t cap = size_t(1) << d.log2cap;
+  TE_HIP_CHECK(hipMemsetAsync(d.vals, 0xFF, sizeof(unsigned) * cap, stream_));
+  TE_HIP_CHECK(hipMemsetAsync(d.seen, 0, sizeof(int) * cap, stream_));
+  d.epoch = 0;
+  for (size_t b = 0; b < batches_.size(); ++b) {
+    const long n = batches_[b]->size();
+    if (!n) continue;
+    devIdsReserve(n);
+    TE_HIP_CHECK(hipMemcpyAsync(d.ids, batches_[b]->slot_ids().data(), sizeof(unsigned) * n, hipMemcpyHostToDevice, stream_));
+    hipLaunchKernelGGL(id_table_insert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream_, d.keys, d.vals, d.log2cap,
+                       d.ids, n, (unsigned)b);
+    TE_HIP_CHECK(hipGetLastError());
+    TE_HIP_CHECK(hipStreamSynchronize(stream_));   // d.ids is reused by the next batch; slot_ids() is pageable memory
+  }
+  d.dirty = false;
+}
+
+bool TargetManager::resolveOnDevice(const unsigned* ids, long n, ResolveCounters& out) {
+  if (batches_.empty() || batches_.size() > (size_t)kIdMaxBatches) return false;
+  for (auto& b : batches_)
+    if (b->size() >= (1L << kIdSlotBits)) return false;
+  DevIds& d = dev_ids_;
+  if (d.dirty) devIdsRebuild();
+  devIdsReserve(n);
+  if (++d.epoch == 0x7fffffff) { TE_HIP_CHECK(hipMemsetAsync(d.seen, 0, sizeof(int) * (size_t(1) << d.log2cap), stream_)); d.epoch = 1; }
+  TE_HIP_CHECK(hipMemcpyAsync(d.ids, ids, sizeof(unsigned) * n, hipMemcpyHostToDevice, stream_));
+  TE_HIP_CHECK(hipMemsetAsync(d.counters, 0, sizeof(ResolveCounters), stream_));
+  hipLaunchKernelGGL(id_resolve_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream_, d.keys, d.vals, d.seen, d.log2cap,
+                     d.ids, n, d.epoch, d.loc, d.counters);
+  TE_HIP_CHECK(hipGetLastError());
+  TE_HIP_CHECK(hipMemcpyAsync(d.h_counters, d.counters, sizeof(ResolveCounters), hipMemcpyDeviceToHost, stream_));
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));
+  out = *d.h_counters;
+  return true;
+}
+
 TargetManager::~TargetManager() {
+  devIdsFree();
   dropSeqGraphs();
   for (auto st : branch_streams_) (void)hipStreamDestroy(st);
   for (auto ev : branch_events_) (void)hipEventDestroy(ev);
@@ -219,6 +303,7 @@ void TargetManager::init(target_t type, unsigned id, double dt0, double t0, cons
     const int b = findOrCreateBatch((int)type, Q, R, chooseLayout((int)type, Q, R, P0, 1), cls);
     const long slot = batches_[(size_t)b]->append(1, &id, t0, P0, false, p0, v0 ? v0 : kZero6, a0 ? a0 : kZero6, cls);
     targets_.set(id, Loc{b, (int)slot});
+    dev_ids_.dirty = true;
     if (verbose_) {
       switch (type) {
         case ANGULAR_RATES: std::cout << "Using angular rates for the orientation" << std::endl; break;
@@ -292,6 +377,7 @@ long TargetManager::initBatch(target_t type, const unsigned* ids, long n, double
   }
   targets_.reserve(targets_.size() + (size_t)k);
   for (long j = 0; j < k; ++j) targets_.set(ids[keep[(size_t)j]], Loc{b, (int)(first + j)});
+  dev_ids_.dirty = true;
   return k;
 }
 
@@ -348,6 +434,7 @@ long TargetManager::initBatchClasses(target_t type, const unsigned* ids, long n,
     for (long j = 0; j < k; ++j) targets_.set(ids2[(size_t)j], Loc{(int)b, (int)(first + j)});
     created += k;
   }
+  dev_ids_.dirty = true;
   return created;
 }
 
@@ -389,6 +476,7 @@ bool TargetManager::erase(unsigned id) {
   const bool was_last = loc.slot == b->size() - 1;
   const unsigned moved = b->erase_slot(loc.slot);
   targets_.erase(id);
+  dev_ids_.dirty = true;
   if (!was_last) targets_.set(moved, Loc{loc.batch, loc.slot});
   return true;
 }
@@ -408,6 +496,7 @@ long TargetManager::eraseBatch(const unsigned* ids, long n) {
     targets_.erase(ids[i]);
   }
   std::vector<std::pair<unsigned, int>> moves;
+  dev_ids_.dirty = true;
   for (size_t b = 0; b < batches_.size(); ++b) {
     if (slots[b].empty()) continue;
     batches_[b]->erase_slots(slots[b].data(), (long)slots[b].size(), moves);
@@ -501,6 +590,29 @@ long TargetManager::updateBatch(const unsigned* ids, long n, double dt, const do
       return n;
     }
   }
+  // ids in any order, possibly several batches, possibly unknown ids: resolved on the device (id_resolve.hpp); a call
+  // that names an id twice keeps the reference's "two consecutive steps" through the host path below
+  if (n >= kDevResolveMin && !verbose_) {
+    ResolveCounters rc;
+    if (resolveOnDevice(ids, n, rc) && !rc.duplicate) {
+      DevIds& d = dev_ids_;
+      if (meas) {
+        TE_HIP_CHECK(hipMemcpyAsync(d.aos, meas, sizeof(double) * 7 * n, hipMemcpyHostToDevice, stream_));
+        batches_[0]->pack_meas_dev(d.aos, n, d.soa, n);
+      }
+      if (meas && has_meas) TE_HIP_CHECK(hipMemcpyAsync(d.mask, has_meas, (size_t)n, hipMemcpyHostToDevice, stream_));
+      long total = 0;
+      for (size_t b = 0; b < nb; ++b) {
+        if (rc.found[b] <= 0) continue;
+        total += rc.found[b];
+        hipLaunchKernelGGL(id_select_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream_, d.loc, n, (int)b, d.idx,
+                           (unsigned char*)nullptr);
+        batches_[b]->step_indexed_dev(d.idx, n, dt, meas ? d.soa : nullptr, n, (meas && has_meas) ? d.mask : nullptr);
+      }
+      TE_HIP_CHECK(hipStreamSynchronize(stream_));   // the caller's host arrays may be reused after return
+      return total;
+    }
+  }
   std::vector<std::vector<int>> slots(nb);
   std::vector<std::vector<long>> src(nb);
   std::vector<std::vector<unsigned char>> seen(nb);
@@ -572,6 +684,47 @@ long TargetManager::getPoseBatch(const unsigned* ids, long n, double* pose, doub
       bt->outputs(nullptr, n, pose, twist, acc, at_time, t1);
       if (found) std::memset(found, 1, (size_t)n);
       return n;
+    }
+  }
+  if (n >= kDevResolveMin) {   // ids resolved on the device; rows come back in the caller's order
+    ResolveCounters rc;
+    if (resolveOnDevice(ids, n, rc)) {
+      DevIds& d = dev_ids_;
+      long total = 0;
+      double* dp = pose ? d.out : nullptr;
+      double* dtw = twist ? d.out + 7 * n : nullptr;
+      double* da = acc ? d.out + 13 * n : nullptr;
+      for (size_t b = 0; b < nb; ++b) {
+        if (rc.found[b] <= 0) continue;
+        total += rc.found[b];
+        hipLaunchKernelGGL(id_select_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream_, d.loc, n, (int)b, d.idx,
+                           (unsigned char*)nullptr);
+        batches_[b]->outputs_indexed_dev(d.idx, n, dp, dtw, da, at_time, t1);
+      }
+      if (total == n) {   // every id known: straight into the caller's arrays
+        if (pose) TE_HIP_CHECK(hipMemcpyAsync(pose, dp, sizeof(double) * 7 * n, hipMemcpyDeviceToHost, stream_));
+        if (twist) TE_HIP_CHECK(hipMemcpyAsync(twist, dtw, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, stream_));
+        if (acc) TE_HIP_CHECK(hipMemcpyAsync(acc, da, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, stream_));
+        TE_HIP_CHECK(hipStreamSynchronize(stream_));
+        if (found) std::memset(found, 1, (size_t)n);
+      } else {            // rows of unknown ids stay as the caller left them
+        std::vector<double> hp(pose ? (size_t)n * 7 : 0), ht(twist ? (size_t)n * 6 : 0), ha(acc ? (size_t)n * 6 : 0);
+        std::vector<int> hloc((size_t)n);
+        if (pose) TE_HIP_CHECK(hipMemcpyAsync(hp.data(), dp, sizeof(double) * 7 * n, hipMemcpyDeviceToHost, stream_));
+        if (twist) TE_HIP_CHECK(hipMemcpyAsync(ht.data(), dtw, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, stream_));
+        if (acc) TE_HIP_CHECK(hipMemcpyAsync(ha.data(), da, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, stream_));
+        TE_HIP_CHECK(hipMemcpyAsync(hloc.data(), d.loc, sizeof(int) * n, hipMemcpyDeviceToHost, stream_));
+        TE_HIP_CHECK(hipStreamSynchronize(stream_));
+        for (long i = 0; i < n; ++i) {
+          const bool ok = hloc[(size_t)i] >= 0;
+          if (found) found[i] = ok ? 1 : 0;
+          if (!ok) continue;
+          if (pose) std::memcpy(pose + i * 7, &hp[(size_t)i * 7], sizeof(double) * 7);
+          if (twist) std::memcpy(twist + i * 6, &ht[(size_t)i * 6], sizeof(double) * 6);
+          if (acc) std::memcpy(acc + i * 6, &ha[(size_t)i * 6], sizeof(double) * 6);
+        }
+      }
+      return total;
     }
   }
   std::vector<std::vector<int>> slots(nb);
@@ -730,6 +883,22 @@ Batch* TargetManager::batchOfType(int type) {
   return nullptr;
 }
 
+long TargetManager::posesToDevice(double* out_dev, long capacity, hipStream_t st) {
+  lock_guard<mutex> lg(target_lock_);
+  long rows = 0;
+  for (auto& b : batches_) rows += b->size();
+  if (!out_dev) return rows;
+  if (capacity < rows) throw std::invalid_argument("target_estimation_amd: posesToDevice: buffer too small");
+  if (st != stream_) throw std::invalid_argument("target_estimation_amd: posesToDevice runs on the manager's stream");
+  long off = 0;
+  for (auto& b : batches_) {
+    if (!b->size()) continue;
+    b->outputs_dev(out_dev + off * 7, nullptr, nullptr, false, 0.0);
+    off += b->size();
+  }
+  return rows;
+}
+
 void TargetManager::setStream(hipStream_t s) {
   lock_guard<mutex> lg(target_lock_);
   for (auto& b : batches_) { b->synchronize(); b->set_stream(s); }
@@ -758,8 +927,11 @@ void TargetManager::stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpe
   if (!use_graph) {
     // Zig-zag over the WHOLE tick: tick s walks batch 0 .. nb-1, tiles forwards; tick s+1 walks batch nb-1 .. 0, tiles
     // backwards, so that what the Infinity Cache still holds at the end of a tick is what the next tick reads first.
+    long state = 0;
+    for (size_t b = 0; b < nb; ++b) state += batches_[b]->state_bytes();
+    const bool zz = state >= Batch::zigzag_min_bytes();   // L2-resident populations keep their tile -> XCD affinity
     for (long s = 0; s < n_ticks; ++s) {
-      const bool rev = seq_flip_;
+      const bool rev = zz && seq_flip_;
       for (size_t k = 0; k < nb; ++k) {
         const size_t b = rev ? nb - 1 - k : k;
         batches_[b]->enqueue_tick(stream_, s, dt, specs[b], query, org, radius, rev);
@@ -814,7 +986,8 @@ void TargetManager::stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpe
         for (size_t b = 0; b < nb; ++b) {
           if (batches_[b]->size() == 0) continue;
           set_deps(none);                                  // a new chain: no predecessor
-          for (long s = 0; s < n_ticks; ++s) batches_[b]->enqueue_tick(cap, s, dt, specs[b], query, org, radius, (s & 1) != 0);
+          const bool zz = batches_[b]->state_bytes() >= Batch::zigzag_min_bytes();
+          for (long s = 0; s < n_ticks; ++s) batches_[b]->enqueue_tick(cap, s, dt, specs[b], query, org, radius, zz && (s & 1) != 0);
           const Nodes tail = captured();
           leaves.insert(leaves.end(), tail.begin(), tail.end());
         }

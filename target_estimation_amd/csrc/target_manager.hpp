@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "batch_store.hpp"
+#include "id_resolve.hpp"
 #include "id_table.hpp"
 
 namespace te {
@@ -127,6 +128,10 @@ class TargetManager {
   Batch* batch(int i) { return batches_[(size_t)i].get(); }
   Batch* batchOfType(int type);
   void setStream(hipStream_t s);
+  hipStream_t stream() const { return stream_; }
+  // pose7 rows (doubles) of every target, batch after batch in slot order, into out_dev [size()][7] on stream `st`
+  // (the gather's send side, pose_gather.hpp); out_dev == null only counts.  Returns the number of rows.
+  long posesToDevice(double* out_dev, long capacity, hipStream_t st);
   void synchronize();
   int dtype() const { return dtype_; }
   bool defaultsLoaded() const { return default_values_loaded_; }
@@ -165,6 +170,23 @@ class TargetManager {
   std::vector<hipStream_t> branch_streams_;   // [0]: the capture stream
   std::vector<hipEvent_t> branch_events_;
   void dropSeqGraphs();
+  // device-side id resolution for the array-of-ids calls (id_resolve.hpp): the table and the staging of one call
+  struct DevIds {
+    unsigned* keys = nullptr; unsigned* vals = nullptr; int* seen = nullptr;
+    int log2cap = 0; bool dirty = true; int epoch = 0;
+    long cap = 0;                       // entries the staging holds
+    unsigned* ids = nullptr; int* loc = nullptr; int* idx = nullptr;
+    double* aos = nullptr; void* soa = nullptr; unsigned char* mask = nullptr; unsigned char* found = nullptr;
+    double* out = nullptr;              // [cap][7 + 6 + 6] getter outputs
+    ResolveCounters* counters = nullptr;
+    ResolveCounters* h_counters = nullptr;   // pinned
+  } dev_ids_;
+  static constexpr long kDevResolveMin = 8192;   // below this the host table is faster than the extra launches
+  void devIdsReserve(long n);
+  void devIdsRebuild();
+  // loc[e] of every id on the device + the per-batch counts on the host; false: not applicable (too many batches)
+  bool resolveOnDevice(const unsigned* ids, long n, ResolveCounters& out);
+  void devIdsFree();
   bool seq_flip_ = false;   // zig-zag across the whole tick: the next eager all-batches tick runs last batch first, tiles backwards
 };
 

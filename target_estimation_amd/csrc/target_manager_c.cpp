@@ -11,6 +11,7 @@
 
 #include "../../include/target_estimation_amd/target_batch_c.h"
 #include "measurement_ingest.hpp"
+#include "pose_gather.hpp"
 #include "target_manager.hpp"
 
 using te::Batch;
@@ -419,6 +420,42 @@ int target_batch_get_est_dev(target_batch_c* b, double* pose_dev, double* twist_
 
 int target_batch_pack_meas_dev(target_batch_c* b, const double* meas_aos_dev, long n, void* meas_soa_dev, long ld) {
   return guarded("target_batch_pack_meas_dev", [&] { BatchLock lk(B(b)); B(b)->pack_meas_dev(meas_aos_dev, n, meas_soa_dev, ld); });
+}
+
+// ---------------------------------------------------------------- pose gather over xGMI (RCCL)
+int target_comm_unique_id(char* out128) {
+  return guarded("target_comm_unique_id", [&] {
+    if (!out128) throw std::invalid_argument("NULL buffer");
+    te::PoseComm::unique_id(out128);
+  });
+}
+
+target_comm_c* target_comm_new(const char* id128, int rank, int world) {
+  te::PoseComm* c = nullptr;
+  guarded("target_comm_new", [&] {
+    if (!id128) throw std::invalid_argument("NULL id");
+    c = new te::PoseComm(id128, rank, world);
+  });
+  return (target_comm_c*)c;
+}
+
+void target_comm_delete(target_comm_c* comm) {
+  if (comm) guarded("target_comm_delete", [&] { delete (te::PoseComm*)comm; });
+}
+
+int target_manager_gather_pose_begin(target_manager_c* self, target_comm_c* comm, int root, const long* counts, double* recv_dev) {
+  return guarded("target_manager_gather_pose_begin", [&] {
+    if (!comm || !counts) throw std::invalid_argument("NULL communicator or counts");
+    ((te::PoseComm*)comm)->begin(M(self), root, counts, recv_dev);
+  });
+}
+
+int target_manager_gather_pose_wait(target_comm_c* comm, float* device_ms) {
+  return guarded("target_manager_gather_pose_wait", [&] {
+    if (!comm) throw std::invalid_argument("NULL communicator");
+    ((te::PoseComm*)comm)->wait();
+    if (device_ms) *device_ms = ((te::PoseComm*)comm)->last_ms();
+  });
 }
 
 // ---------------------------------------------------------------- measurement ingest

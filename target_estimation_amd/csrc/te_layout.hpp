@@ -48,6 +48,50 @@ enum Layout : int { LAYOUT_FULL = 0, LAYOUT_PACKED = 1, LAYOUT_SEPARABLE = 2, LA
 constexpr int model_n(int type) { return type == UNIFORM_VELOCITY ? 6 : type == UNIFORM_ACCELERATION ? 9 : type == ANGULAR_RATES ? 18 : 12; }
 constexpr int model_m(int type) { return (type == UNIFORM_VELOCITY || type == UNIFORM_ACCELERATION) ? 3 : 6; }
 
+// Position of Q(r, c) / R(r, c) inside one parameter-class row [Q | R] of a batch's (Q, R) table.  Dense layouts: the
+// full matrices, row-major.  Separable layouts: only the entries inside an axis group (the others are zero by the
+// layout's precondition), in row-major order of (r, c): 15 / 30 / 60 / 60 contiguous words (UV / UA / AV / AR) instead
+// of 45 / 90 / 180 / 360 scattered ones -- what a lane of the per-class kernel fetches for its target.
+constexpr int qr_q_count(int type, bool sep) {
+  const int n = model_n(type);
+  if (!sep) return n * n;
+  int k = 0;
+  for (int r = 0; r < n; ++r)
+    for (int c = 0; c < n; ++c) k += group_of(type, r) == group_of(type, c) ? 1 : 0;
+  return k;
+}
+constexpr int qr_q_word(int type, bool sep, int r, int c) {
+  const int n = model_n(type);
+  if (!sep) return r * n + c;
+  if (group_of(type, r) != group_of(type, c)) return -1;
+  int k = 0;
+  for (int rr = 0; rr < n; ++rr)
+    for (int cc = 0; cc < n; ++cc) {
+      if (rr == r && cc == c) return k;
+      k += group_of(type, rr) == group_of(type, cc) ? 1 : 0;
+    }
+  return -1;
+}
+constexpr int qr_r_word(int type, bool sep, int r, int c) {   // r, c < m: the measurement rows are state rows 0..m-1
+  const int m = model_m(type);
+  if (!sep) return qr_q_count(type, false) + r * m + c;
+  if (group_of(type, r) != group_of(type, c)) return -1;
+  int k = qr_q_count(type, true);
+  for (int rr = 0; rr < m; ++rr)
+    for (int cc = 0; cc < m; ++cc) {
+      if (rr == r && cc == c) return k;
+      k += group_of(type, rr) == group_of(type, cc) ? 1 : 0;
+    }
+  return -1;
+}
+constexpr int qr_words(int type, bool sep) {
+  const int m = model_m(type);
+  int k = qr_q_count(type, sep);
+  for (int r = 0; r < m; ++r)
+    for (int c = 0; c < m; ++c) k += (!sep || group_of(type, r) == group_of(type, c)) ? 1 : 0;
+  return k;
+}
+
 // PK_ = symmetric-packed storage: only the upper triangle of P (r <= c, row-major, N(N+1)/2 words) is
 // kept in HBM.  G = 1 (thread per target): the mirror into the registers is a register rename.
 // G > 1: lane i of a target stores the i-th slice of ceil(N(N+1)/2 / G) words of the triangle; after
@@ -137,7 +181,23 @@ struct Cfg {
     return t;
   }
   static constexpr WordTable PWORD = make_table();
-  static constexpr int QR_WORDS = N * N + K * K;
+  static constexpr int QR_WORDS = qr_words(M::TYPE, SEP);   // words of one parameter-class row
+  struct QTable { int v[N][N]; };
+  struct RTable { int v[K][K]; };
+  static constexpr QTable make_qtable() {
+    QTable t{};
+    for (int r = 0; r < N; ++r)
+      for (int c = 0; c < N; ++c) t.v[r][c] = qr_q_word(M::TYPE, SEP, r, c);
+    return t;
+  }
+  static constexpr RTable make_rtable() {
+    RTable t{};
+    for (int r = 0; r < K; ++r)
+      for (int c = 0; c < K; ++c) t.v[r][c] = qr_r_word(M::TYPE, SEP, r, c);
+    return t;
+  }
+  static constexpr QTable QWORD = make_qtable();
+  static constexpr RTable RWORD = make_rtable();
   // wavefronts per workgroup: as many as keep static LDS under 64 KiB
   static constexpr long LDS4 = (long)(4 * (QR_WORDS + EX_WORDS) + 1) * (long)sizeof(T);
   static constexpr long LDS2 = (long)(2 * (QR_WORDS + EX_WORDS) + 1) * (long)sizeof(T);

@@ -61,3 +61,79 @@ def all_gather_rows(local, n_total, group=None):
         lo, hi = shard_bounds(n_total, r, world)
         out.append(full[r * max_rows: r * max_rows + (hi - lo)])
     return torch.cat(out, 0)
+
+
+class PoseGather:
+    """The library's own gather of pose7 rows over xGMI (csrc/pose_gather.cpp: direct ncclSend / ncclRecv on a second
+    stream behind an event, overlapped with the following ticks).  torch.distributed is used only to hand rank 0's
+    RCCL id and the per-rank row counts to every rank; with world size 1 (or no process group) it is not needed.
+
+        g = PoseGather(mgr)           # collective: every rank
+        g.begin()                     # enqueue; returns at once, the next ticks may be issued
+        ...                           # mgr steps on
+        poses = g.wait()              # root: CUDA double tensor [total, 7] (ranks in order, batch then slot order)
+    """
+
+    def __init__(self, manager, root=0, group=None):
+        import ctypes as C
+        from . import capi
+        self._lib = capi.lib()
+        self._mgr = manager
+        self.root = root
+        have_pg = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if have_pg else 0
+        self.world = dist.get_world_size(group) if have_pg else 1
+        ident = C.create_string_buffer(128)
+        if self.rank == 0:
+            if self._lib.target_comm_unique_id(ident) != 0:
+                raise RuntimeError("target_comm_unique_id failed: %s" % capi.last_error())
+        if self.world > 1:
+            box = [bytes(ident.raw)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = C.create_string_buffer(box[0], 128)
+        self._h = self._lib.target_comm_new(ident, self.rank, self.world)
+        if not self._h:
+            raise RuntimeError("target_comm_new failed: %s" % capi.last_error())
+        self._group = group
+        self._recv = None
+        self._counts = None
+
+    def counts(self):
+        """rows per rank (exchanged once per call of begin(): targets may have been created or erased)"""
+        mine = int(self._mgr.size())
+        if self.world == 1:
+            return [mine]
+        box = [None] * self.world
+        dist.all_gather_object(box, mine, group=self._group)
+        return [int(v) for v in box]
+
+    def begin(self, counts=None):
+        import ctypes as C
+        from . import capi
+        counts = self.counts() if counts is None else list(counts)
+        total = sum(counts)
+        arr = (C.c_long * self.world)(*counts)
+        ptr = None
+        if self.rank == self.root:
+            if self._recv is None or self._recv.shape[0] != total:
+                self._recv = torch.empty((total, 7), dtype=torch.float64, device="cuda")
+            ptr = self._recv.data_ptr()
+        if self._lib.target_manager_gather_pose_begin(self._mgr.handle, self._h, int(self.root), arr, ptr) != 0:
+            raise RuntimeError("target_manager_gather_pose_begin failed: %s" % capi.last_error())
+        self._counts = counts
+
+    def wait(self):
+        """Blocks until the gather has finished; returns (poses or None, device milliseconds of the gather)."""
+        import ctypes as C
+        from . import capi
+        ms = C.c_float()
+        if self._lib.target_manager_gather_pose_wait(self._h, C.byref(ms)) != 0:
+            raise RuntimeError("target_manager_gather_pose_wait failed: %s" % capi.last_error())
+        return (self._recv if self.rank == self.root else None), float(ms.value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.target_comm_delete(self._h)
+            self._h = None
+
+    __del__ = close

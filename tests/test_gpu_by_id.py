@@ -1,0 +1,116 @@
+"""The array-of-ids entry points with ids in ARBITRARY order at a size where they are resolved on the device
+(csrc/id_resolve.hpp; >= 8192 ids): several batches in one manager, unknown ids, masks, an id named twice, getters,
+and the table's rebuild after erase / create.  GPU vs the oracle (one oracle batch per model)."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import synth_stream
+from test_gpu_parity import TOL
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+te = pytest.importorskip("target_estimation_amd")
+
+
+def _cmp(mgr, ids, orc, dtype, what):
+    t = TOL[dtype]
+    x, P = mgr.get_state_batch(ids)
+    xo, Po = orc.state()
+    assert (np.abs(x - xo) - (t["x_atol"] + t["x_rtol"] * np.abs(xo))).max() <= 0, what
+    assert (np.abs(P - Po) / np.abs(Po).max(axis=(1, 2), keepdims=True)).max() <= t["P_rel"], what
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_random_order_by_id_calls_resolved_on_device(models, dtype):
+    names = ["uniform_velocity", "angular_rates"]
+    N = [12000, 9000]
+    dt, steps = 0.004, 5
+    rng = np.random.default_rng(3)
+    mgr = te.TargetManager(dtype=dtype)
+    all_ids = rng.permutation(200000)[: sum(N)].astype(np.uint32)
+    parts, base = [], 0
+    for name, n in zip(names, N):
+        m = models[name]
+        p0, meas = synth_stream(name, n, steps, seed=5 + n)
+        ids = all_ids[base:base + n]
+        base += n
+        assert mgr.init_batch(ids, dt, 0.0, p0, type=m["model"], Q=m["Q"], R=m["R"], P0=m["P"]) == n
+        parts.append(dict(name=name, ids=ids, p0=p0, meas=meas, orc=oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], p0, dt, dtype=dtype)))
+    assert len(mgr.batches()) == 2
+    ids_all = np.concatenate([p["ids"] for p in parts])
+    unknown = np.arange(500000, 500050, dtype=np.uint32)
+    for s in range(steps):
+        meas_all = np.concatenate([p["meas"][s] for p in parts])
+        order = rng.permutation(len(ids_all))
+        take = order[: len(order) * 3 // 4] if s % 2 else order        # a subset on odd ticks
+        call_ids = np.concatenate([ids_all[take], unknown])              # + ids that do not exist
+        call_meas = np.concatenate([meas_all[take], np.zeros((len(unknown), 7))])
+        has = (rng.random(len(call_ids)) < 0.8).astype(np.uint8) if s >= 2 else None
+        got = mgr.update_batch(call_ids, dt, call_meas, has)
+        assert got == len(take)
+        # the same steps in the oracles
+        off = 0
+        for p in parts:
+            n = len(p["ids"])
+            stepped = np.zeros(n, dtype=bool); h = np.zeros(n, dtype=np.uint8)
+            sel = take[(take >= off) & (take < off + n)] - off
+            stepped[sel] = True
+            if has is None:
+                h[sel] = 1
+            else:
+                pos = {int(g): k for k, g in enumerate(take)}
+                h[sel] = [has[pos[int(g + off)]] for g in sel]
+            # targets not named this tick do not move: step only the named ones, one by one
+            for i in np.nonzero(stepped)[0]:
+                if h[i]:
+                    p["orc"]._f("orc_target_add_measurement")(p["orc"]._at(int(i)), float(dt), oracle.oracle._dp(np.ascontiguousarray(p["meas"][s][i])))
+                else:
+                    p["orc"]._f("orc_target_update")(p["orc"]._at(int(i)), float(dt))
+            off += n
+    for p in parts:
+        _cmp(mgr, p["ids"], p["orc"], dtype, p["name"])
+    # getters by id, random order with unknown ids: rows of unknown ids are left as they were, found = False
+    order = rng.permutation(len(ids_all))
+    q = np.concatenate([ids_all[order][:15000], unknown])
+    rng.shuffle(q)
+    pose, twist, acc, found = mgr.get_est_batch(q)
+    known = np.isin(q, ids_all)
+    np.testing.assert_array_equal(found, known)
+    assert np.isnan(pose[~known]).all() and np.isfinite(pose[known]).all()
+    off = 0
+    for p in parts:
+        po = p["orc"].pose()
+        lut = {int(i): k for k, i in enumerate(p["ids"])}
+        rows = [r for r, v in enumerate(q) if int(v) in lut]
+        want = np.array([po[lut[int(q[r])]] for r in rows])
+        np.testing.assert_allclose(pose[rows], want, atol=TOL[dtype]["out_atol"])
+    # an id named twice in one call = two consecutive steps (host path), same answer as two calls
+    twice = np.concatenate([parts[0]["ids"][:9000], parts[0]["ids"][:10]])
+    m2 = np.concatenate([parts[0]["meas"][0][:9000], parts[0]["meas"][1][:10]])
+    assert mgr.update_batch(twice, dt, m2) == len(twice)
+    o = parts[0]["orc"]
+    for i in range(9000):
+        o._f("orc_target_add_measurement")(o._at(i), float(dt), oracle.oracle._dp(np.ascontiguousarray(parts[0]["meas"][0][i])))
+    for i in range(10):
+        o._f("orc_target_add_measurement")(o._at(i), float(dt), oracle.oracle._dp(np.ascontiguousarray(parts[0]["meas"][1][i])))
+    _cmp(mgr, parts[0]["ids"], o, dtype, "after a call that names ids twice")
+    # erase + create: the device table is rebuilt; erased ids are unknown, moved records are found where they now live
+    gone = parts[1]["ids"][::3]
+    assert mgr.erase_batch(gone) == len(gone)
+    new_ids = np.arange(600000, 600000 + 3000, dtype=np.uint32)
+    m = models[names[0]]
+    assert mgr.init_batch(new_ids, dt, 0.0, parts[0]["p0"][:3000], type=m["model"], Q=m["Q"], R=m["R"], P0=m["P"]) == 3000
+    q = np.concatenate([gone[:100], parts[1]["ids"][1::3], new_ids])
+    rng.shuffle(q)
+    assert mgr.update_batch(q, dt, None) == len(q) - 100          # predict-only by id
+    pose, _, _, found = mgr.get_est_batch(q)
+    np.testing.assert_array_equal(found, ~np.isin(q, gone))
+    keep_rows = np.arange(len(parts[1]["ids"]))[1::3]
+    for i in keep_rows:
+        parts[1]["orc"]._f("orc_target_update")(parts[1]["orc"]._at(int(i)), float(dt))
+    x, P = mgr.get_state_batch(parts[1]["ids"][1::3])
+    xo, Po = parts[1]["orc"].state()
+    t = TOL[dtype]
+    assert (np.abs(x - xo[keep_rows]) - (t["x_atol"] + t["x_rtol"] * np.abs(xo[keep_rows]))).max() <= 0
+    mgr.close()

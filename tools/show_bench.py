@@ -20,6 +20,8 @@ if "parity" in d:
 for e in d.get("extra", []):
     if "error" in e:
         print("  %-16s ERROR %s" % (e["name"], e["error"]))
+    elif e["name"] == "gather_pose":
+        print("  gather_pose:", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in e.items()})
     else:
         print("  %-16s %-3s %9d  %9.4g c/s  %8.4f ms  %6.0f GB/s  frac %.3f  %-12s %s" % (
             e["name"], e["dtype"], e["targets_per_gpu"], e["cycles_per_s"], e["ms_per_step"], e["achieved_gbs"], e["roofline_frac"],
