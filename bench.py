@@ -741,6 +741,15 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args, sys.argv[1:]))
 
+    # stdout carries ONE JSON line and nothing else: libraries that chat on stdout (RCCL prints a version banner when a
+    # communicator is created) are sent to stderr for the whole run; the line goes to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
     import torch
     dist, rank, world = init_ranks(args, torch)
 
@@ -750,10 +759,10 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"metric": "KF predict+update cycles/sec over N targets", "value": None, "unit": "cycles/s", "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": median(wall) * 1e3 / args.steps,
-                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-                              "data": "dry-run: no device work", "config": {"workload": "dry-run of the rank start-up and timing protocol"}}))
+            emit({"metric": "KF predict+update cycles/sec over N targets", "value": None, "unit": "cycles/s", "n_gpus": world,
+                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": median(wall) * 1e3 / args.steps,
+                  "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+                  "data": "dry-run: no device work", "config": {"workload": "dry-run of the rank start-up and timing protocol"}})
         return
 
     import target_estimation_amd as te
@@ -869,7 +878,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
 
 
 if __name__ == "__main__":
