@@ -5,7 +5,7 @@ namespace te {
 
 const Ops* get_ops_ar(int dtype, int g) {
   if (dtype == F64) {
-    if (g == 0) g = 3;   // profiles/r01_layout_sweep.txt
+    if (g == 0) g = 6;   // 184 VGPRs, 2 waves per SIMD (G = 3 needs 370: one); same speed (profiles/r02_layout_sweep.txt)
     switch (g) {
       case 3: return OpsImpl<ModelAR, double, 3>::get();
       case 6: return OpsImpl<ModelAR, double, 6>::get();

@@ -5,7 +5,7 @@ namespace te {
 
 const Ops* get_ops_av(int dtype, int g) {
   if (dtype == F64) {
-    if (g == 0) g = 3;   // profiles/r01_layout_sweep.txt
+    if (g == 0) g = 6;   // 178 VGPRs, 2 waves per SIMD (G = 3 needs 270: one); profiles/r02_layout_sweep.txt
     switch (g) {
       case 3: return OpsImpl<ModelAV, double, 3>::get();
       case 6: return OpsImpl<ModelAV, double, 6>::get();

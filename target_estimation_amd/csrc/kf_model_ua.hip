@@ -16,7 +16,7 @@ const Ops* get_ops_ua(int dtype, int g) {
       default: return nullptr;
     }
   } else if (dtype == F32) {
-    if (g == 0) g = 1;
+    if (g == 0) g = 3;   // 90 VGPRs (5 waves per SIMD); G = 1 needs 210 and is no faster (profiles/r02_layout_sweep.txt)
     switch (g) {
       case 1: return OpsImpl<ModelUA, float, 1>::get();
       case 101: return OpsImpl<ModelUA, float, 1, LAYOUT_PACKED>::get();  // symmetric-packed P

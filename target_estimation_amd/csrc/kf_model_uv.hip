@@ -5,7 +5,7 @@ namespace te {
 
 const Ops* get_ops_uv(int dtype, int g) {
   if (dtype == F64) {
-    if (g == 0) g = 3;
+    if (g == 0) g = 1;   // thread per target: 140 / 112 VGPRs (3-4 waves per SIMD), 3-9 % faster than G = 3 at 10^6 targets (profiles/r02_layout_sweep.txt)
     switch (g) {
       case 1: return OpsImpl<ModelUV, double, 1>::get();
       case 101: return OpsImpl<ModelUV, double, 1, LAYOUT_PACKED>::get();  // symmetric-packed P
@@ -16,7 +16,7 @@ const Ops* get_ops_uv(int dtype, int g) {
       default: return nullptr;
     }
   } else if (dtype == F32) {
-    if (g == 0) g = 3;
+    if (g == 0) g = 1;   // thread per target: 140 / 112 VGPRs (3-4 waves per SIMD), 3-9 % faster than G = 3 at 10^6 targets (profiles/r02_layout_sweep.txt)
     switch (g) {
       case 1: return OpsImpl<ModelUV, float, 1>::get();
       case 101: return OpsImpl<ModelUV, float, 1, LAYOUT_PACKED>::get();  // symmetric-packed P

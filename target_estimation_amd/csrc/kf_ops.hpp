@@ -30,6 +30,7 @@ struct StepParams {
   double q_radius = 0;
   double* q_delta = nullptr;
   double* q_pose = nullptr;
+  int nt_meas = 0;        // nontemporal measurement loads (kf_step.hpp StepArgs::nt_meas)
   int reverse = 0;        // walk the tiles last-to-first (zig-zag between consecutive ticks: kf_step.hpp StepArgs)
 };
 

@@ -25,6 +25,8 @@ struct OpsImpl {
     a.q_origin[0] = p.q_origin[0]; a.q_origin[1] = p.q_origin[1]; a.q_origin[2] = p.q_origin[2];
     a.q_radius = p.q_radius; a.q_delta = p.q_delta; a.q_pose = p.q_pose;
     a.reverse = p.reverse;
+    static const int nt_env = [] { const char* e = std::getenv("TE_NT_MEAS"); return e ? std::atoi(e) : -1; }();
+    a.nt_meas = nt_env >= 0 ? nt_env : p.nt_meas;
     if (p.q_delta && (p.idx || p.n_ticks > 1))
       throw std::runtime_error("target_estimation_amd: the fused query needs a dense single-tick launch");
     const long waves = (p.n + C::TPW - 1) / C::TPW;

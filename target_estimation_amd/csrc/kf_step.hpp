@@ -59,7 +59,12 @@ struct StepArgs {
   // tick (tools/zigzag_ceiling.hip: 480 MB of state in place 5.3 -> 6.6 TB/s, 960 MB 5.4 -> 6.0); results are
   // independent of the order (targets are independent).
   int reverse;
+  // measurements are read once per tick: nt_meas != 0 loads them with the nontemporal policy so that they do not push
+  // state out of the Infinity Cache (set for batches large enough to zig-zag; TE_NT_MEAS overrides)
+  int nt_meas;
 };
+
+template <typename T> __device__ __forceinline__ T load_meas(const T* p, int nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
 
 template <typename T> struct Vec16;
 template <> struct Vec16<double> { using type = double2; };
@@ -258,11 +263,11 @@ __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kern
 #pragma unroll
     for (int qq = 0; qq < KPL; ++qq) {
       const int r = i + G * qq;
-      if (!M::ANGULAR || r < 3) ymeas_own[qq] = meas_t[(long)r * a.meas_ld + entry];
+      if (!M::ANGULAR || r < 3) ymeas_own[qq] = load_meas(&meas_t[(long)r * a.meas_ld + entry], a.nt_meas);
     }
     if constexpr (M::ANGULAR) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) qmeas[c] = meas_t[(long)(3 + c) * a.meas_ld + entry];
+      for (int c = 0; c < 4; ++c) qmeas[c] = load_meas(&meas_t[(long)(3 + c) * a.meas_ld + entry], a.nt_meas);
     }
     if (has_t != nullptr) hmask = has_t[entry];
   }

@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
   unsigned char hmask = 1;
   if (valid && meas_t != nullptr) {
 #pragma unroll
-    for (int c = 0; c < MW; ++c) ymeas[c] = meas_t[(long)c * a.meas_ld + entry];
+    for (int c = 0; c < MW; ++c) ymeas[c] = load_meas(&meas_t[(long)c * a.meas_ld + entry], a.nt_meas);
     if (has_t != nullptr) hmask = has_t[entry];
   }
   const bool has = valid && meas_t != nullptr && hmask != 0;

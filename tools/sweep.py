@@ -32,8 +32,11 @@ def main():
                 for g in LANES[model][dtype]:
                     bench.WORKLOADS["_sweep"] = ("sweep", model, dtype, n, 7)
                     steps = args.steps if n <= 200000 else max(20, args.steps // 5)
-                    r = bench.run_workload(te, torch, "_sweep", steps, 10, g, stream_ticks=8)
-                    r.pop("_mgr")
+                    try:
+                        r = bench.run_workload(te, torch, "_sweep", steps, 10, g, stream_ticks=8, reps=2)
+                    except Exception as exc:
+                        print("%-22s %-4s %3d %9d  ERROR %s" % (model, dtype, g, n, str(exc)[:80]), flush=True)
+                        continue
                     print("%-22s %-4s %3d %9d %10.2f %12.4g %9.0f %6.3f" % (model, dtype, g, n, r["device_ms_per_launch"] * 1e3,
                           r["cycles_per_s"], r["achieved_gbs"], r["achieved_gbs"] / 8000.0), flush=True)
                     torch.cuda.empty_cache()
