@@ -434,14 +434,19 @@ def run_mixed(te, torch, name, steps, warmup, dist=None, rank=0, world=1, stream
     per = [[] for _ in range(nb)]
     for i, j in enumerate(slots):
         per[j].append(evs[i].elapsed_time(evs[i + 1]))
+    # An event between two launches costs a few microseconds of its own, so the periods above overstate the kernels.  What
+    # is exact is the tick's device time over the timed region; it is split between the kernels in the ratio of their
+    # event periods (the launch boundaries inside the tick stay included).
+    period = [sum(p) / len(p) for p in per]
     res["kernels"] = []
     for j, (b, m) in enumerate(zip(batches, models)):
-        ms = sum(per[j]) / len(per[j])
+        ms = res["device_ms_per_step"] * period[j] / sum(period)
         per_unit = b.algorithmic_bytes
         res["kernels"].append(dict(kernel=kernel_name(b, m), model=m, units_per_launch=b.size, algorithmic_bytes_per_unit=per_unit,
                                    avg_launch_ms=ms, achieved_gbs=per_unit * b.size / (ms * 1e-3) / 1e9,
                                    frac=per_unit * b.size / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                   note=("timed without the fused query" if intersect else "")))
+                                   event_period_ms=period[j],
+                                   note=("share measured without the fused query" if intersect else "")))
     for b in batches:
         p, _, _ = b.get_est(twist=False, acc=False)
         assert torch.isfinite(p).all()
@@ -796,8 +801,9 @@ def main():
         "roofline": {"bound": "hbm", "achieved": dom["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": dom["achieved_gbs"] / HBM_PEAK_GBS, "traffic": dom.get("traffic"),
                      "kernel": dom["kernel"],
-                     "kernel_note": "dominant kernel of the tick (largest share of the bytes); avg launch duration from HIP events on the launch "
-                                    "stream between consecutive launches, in the same launch order as the timed region, right after it",
+                     "kernel_note": "dominant kernel of the tick (largest share of the bytes).  avg_launch_ms = the tick's device time over the "
+                                    "timed region (HIP events on the launch stream) x this kernel's share of it; the share comes from one HIP event "
+                                    "between consecutive launches in a pass with the timed region's launch order, right after it",
                      "algorithmic_bytes_per_unit": dom["algorithmic_bytes_per_unit"], "units_per_launch": dom["units_per_launch"],
                      "avg_launch_ms": dom["avg_launch_ms"],
                      "bytes_rule": "bytes the kernel reads + writes per target: 2n + 2|P stored| + measurement words read (3 linear, 7 angular) "

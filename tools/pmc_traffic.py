@@ -42,16 +42,29 @@ def one_pass(workload, counter, out, steps, extra_args):
     os.makedirs(d, exist_ok=True)
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", counter, "--",
            "python3", os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", str(steps), "--warmup", "2", "--reps", "1",
-           "--no-cpu", "--extra", ""] + extra_args
+           "--no-cpu", "--no-gather", "--extra", ""] + extra_args
     env = dict(os.environ, TMPDIR="/tmp")
     with open(os.path.join(out, workload, counter + ".stderr.txt"), "w") as err, open(os.path.join(out, workload, counter + ".stdout.txt"), "w") as so:
         rc = subprocess.call(cmd, stdout=so, stderr=err, env=env, cwd="/tmp")
     rows = {}
+    kept = []
+    header = None
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
+        rd = csv.DictReader(open(f))
+        header = rd.fieldnames
+        for r in rd:
             k = short_kernel(r["Kernel_Name"])
             if k and r["Counter_Name"] == counter:
                 rows.setdefault((k, r.get("Grid_Size", "")), []).append(float(r["Counter_Value"]))
+                kept.append(r)
+    # keep the raw rows of the step kernels only (the full CSVs of 80 passes do not fit gpurun's 64 MiB return limit)
+    if header:
+        with open(os.path.join(out, workload, counter + "_counter_collection.csv"), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=header)
+            w.writeheader()
+            w.writerows(kept)
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
     return rc, rows
 
 
@@ -72,8 +85,9 @@ def main():
                 failures.append("%s %s rc=%d rows=%d" % (wl, counter, rc, len(rows)))
                 print("FAILED", failures[-1], flush=True)
                 continue
-            for (k, grid), v in rows.items():
-                e = per.setdefault(k, {"grid": grid})
+            for (k, grid), v in sorted(rows.items(), key=lambda kv: int(kv[0][1] or 0)):   # one kernel at two grids: the larger one wins
+                e = per.setdefault(k, {})
+                e["grid"] = grid
                 # skip the first launches (cold caches / first touch): average the second half
                 tail = v[len(v) // 2:]
                 avg = sum(tail) / len(tail)
