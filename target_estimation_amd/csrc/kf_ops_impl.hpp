@@ -35,6 +35,20 @@ struct OpsImpl {
     const int wpb_dense = waves <= small_grid ? 1 : C::WPB;
     const unsigned blocks = (unsigned)((waves + wpb_dense - 1) / wpb_dense);
     if (p.n_ticks > 1 && p.idx) throw std::runtime_error("target_estimation_amd: fused multi-tick launches are dense only");
+    // Two temporally fused instantiations do not fit the register file and would spill to scratch (profiles/
+    // r02_kernel_resources.txt: 228 / 116 B per lane): for them a fused request is served tick by tick -- same results.
+    constexpr bool kFusedSpills = (M::TYPE == ANGULAR_RATES && sizeof(T) == 8 && G == 3 && LAYOUT == LAYOUT_PACKED) ||
+                                  (M::TYPE == ANGULAR_VELOCITIES && sizeof(T) == 4 && G == 1 && LAYOUT == LAYOUT_FULL);
+    if (kFusedSpills && p.n_ticks > 1) {
+      StepParams q = p;
+      q.n_ticks = 1;
+      for (int t = 0; t < p.n_ticks; ++t) {
+        q.meas = p.meas ? static_cast<const char*>(p.meas) + (size_t)t * (size_t)p.tick_stride * sizeof(T) : nullptr;
+        q.has_meas = p.has_meas ? p.has_meas + (long)t * p.has_stride : nullptr;
+        step(q, s);
+      }
+      return;
+    }
     if (p.cls && (p.n_ticks > 1 || p.q_delta))
       throw std::runtime_error("target_estimation_amd: a batch with several (Q, R) classes steps one tick per launch, without the fused query");
     if constexpr (C::SEP) {
@@ -59,8 +73,10 @@ struct OpsImpl {
         hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, true, false, false, true>), dim3(blocks), dim3(wpb_dense * 64), 0, s, a);
       else if (p.cls)
         hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, false, false, false, true>), dim3(blocks), dim3(wpb_dense * 64), 0, s, a);
-      else if (p.n_ticks > 1)
-        hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, false, true>), dim3(blocks), dim3(wpb_dense * 64), 0, s, a);
+      else if (p.n_ticks > 1) {
+        if constexpr (!kFusedSpills)
+          hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, false, true>), dim3(blocks), dim3(wpb_dense * 64), 0, s, a);
+      }
       else if (p.idx)
         hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, true>), dim3(blocks), dim3(wpb_dense * 64), 0, s, a);
       else if (p.q_delta)
