@@ -313,7 +313,15 @@ void Batch::step_sequence(long n_ticks, double dt, const void* meas_base, long t
       if (g.n_ticks == n_ticks && g.tick_stride == tick_stride && g.ld == ld && g.has_stride == has_stride && g.n == n_ &&
           g.dt == dt && g.meas_base == meas_base && g.has_base == has_base && g.rec == d_rec_ && g.ring_ticks == ring_ticks) hit = &g;
     if (!hit) {
-      if (graphs_.size() >= 64) drop_graphs();   // e.g. a ring of 4096 ticks replayed in 64-tick blocks
+      if (graphs_.size() >= 64) {   // e.g. a ring of 4096 ticks replayed in 64-tick blocks: evict the least recently used one
+        size_t victim = 0;
+        for (size_t k = 1; k < graphs_.size(); ++k)
+          if (graphs_[k].last_use < graphs_[victim].last_use) victim = k;
+        TE_HIP_CHECK(hipStreamSynchronize(stream_));   // it may still be running
+        (void)hipGraphExecDestroy(graphs_[victim].exec);
+        (void)hipGraphDestroy(graphs_[victim].graph);
+        graphs_.erase(graphs_.begin() + (long)victim);
+      }
       if (!cap_stream_) TE_HIP_CHECK(hipStreamCreateWithFlags(&cap_stream_, hipStreamNonBlocking));
       GraphEntry e{n_ticks, tick_stride, ld, has_stride, n_, dt, meas_base, has_base, d_rec_, nullptr, nullptr, ring_ticks};
       TE_HIP_CHECK(hipStreamBeginCapture(cap_stream_, hipStreamCaptureModeThreadLocal));
@@ -334,6 +342,7 @@ void Batch::step_sequence(long n_ticks, double dt, const void* meas_base, long t
       graphs_.push_back(e);
       hit = &graphs_.back();
     }
+    hit->last_use = ++graph_clock_;
     if (use_graph == 2) return;  // record only
     TE_HIP_CHECK(hipGraphLaunch(hit->exec, stream_));
     flip_ = (n_ticks & 1) != 0;   // the graph's last tick ran forwards (odd count) or backwards

@@ -207,8 +207,10 @@ class Batch {
     hipGraphExec_t exec;
     hipGraph_t graph;
     long ring_ticks;
+    unsigned long last_use = 0;
   };
   std::vector<GraphEntry> graphs_;
+  unsigned long graph_clock_ = 0;   // recorded sequences are evicted least-recently-used first (64 kept)
   hipStream_t cap_stream_ = nullptr;
   void drop_graphs();
   // queue of one-target steps (reference C ABI) and the cache that serves the one-target getters

@@ -960,7 +960,12 @@ void TargetManager::stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpe
       if (ok) { hit = &g; break; }
     }
     if (!hit) {
-      if (seq_graphs_.size() >= 8) dropSeqGraphs();
+      if (seq_graphs_.size() >= 8) {   // evict the oldest recording (they are appended in order of creation)
+        TE_HIP_CHECK(hipStreamSynchronize(stream_));
+        (void)hipGraphExecDestroy(seq_graphs_.front().exec);
+        (void)hipGraphDestroy(seq_graphs_.front().graph);
+        seq_graphs_.erase(seq_graphs_.begin());
+      }
       if (branch_streams_.empty()) {
         hipStream_t st; TE_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         branch_streams_.push_back(st);

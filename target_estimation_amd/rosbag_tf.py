@@ -17,7 +17,7 @@ import struct
 
 import numpy as np
 
-OP_MSG, OP_CHUNK, OP_CONN = 0x02, 0x05, 0x07
+OP_MSG, OP_BAG_HEADER, OP_CHUNK, OP_CHUNK_INFO, OP_CONN = 0x02, 0x03, 0x05, 0x06, 0x07
 
 
 def _fields(header):
@@ -61,12 +61,49 @@ def parse_tf_message(data):
         pos += 56
         # toSec(), include/target_estimation/utils.hpp:59-62
         out.append((float(sec) + 1e-9 * float(nsec), frame, child, np.array(vals, dtype=np.float64)))
+    if pos != len(data):   # the record's data_len was written by the recorder: the parse must consume it exactly
+        raise ValueError("TFMessage of %d bytes parsed to %d" % (len(data), pos))
     return out
 
 
-def read_tf(path, topic="/tf"):
+def declared_counts(path):
+    """What the bag says about itself, read from its INDEX section (not from the chunks read_tf walks): the bag header
+    record (op 0x03: index_pos, conn_count, chunk_count), the connection records behind index_pos and the chunk-info
+    records (op 0x06), whose data lists (connection id, message count) pairs per chunk.  Returns
+    {topic: messages the recorder counted}, conn_count, chunk_count."""
+    buf = open(path, "rb").read()
+    magic = b"#ROSBAG V2.0\n"
+    if not buf.startswith(magic):
+        raise ValueError("not a rosbag v2 file: %s" % path)
+    first = next(_records(buf, len(magic)))[0]
+    if first.get("op", b"\xff")[0] != OP_BAG_HEADER:
+        raise ValueError("the first record is not the bag header")
+    index_pos = struct.unpack("<Q", first["index_pos"])[0]
+    conn_count = struct.unpack("<I", first["conn_count"])[0]
+    chunk_count = struct.unpack("<I", first["chunk_count"])[0]
+    topics, counts, chunks = {}, {}, 0
+    for fields, data in _records(buf, index_pos):
+        op = fields.get("op", b"\xff")[0]
+        if op == OP_CONN:
+            topics[struct.unpack("<I", fields["conn"])[0]] = fields["topic"].decode()
+        elif op == OP_CHUNK_INFO:
+            chunks += 1
+            n = struct.unpack("<I", fields["count"])[0]
+            for k in range(n):
+                conn, cnt = struct.unpack_from("<II", data, 8 * k)
+                counts[conn] = counts.get(conn, 0) + cnt
+    if len(topics) != conn_count or chunks != chunk_count:
+        raise ValueError("index section: %d connections / %d chunk infos, header says %d / %d" % (len(topics), chunks, conn_count, chunk_count))
+    per_topic = {}
+    for conn, cnt in counts.items():
+        per_topic[topics[conn]] = per_topic.get(topics[conn], 0) + cnt
+    return per_topic, conn_count, chunk_count
+
+
+def read_tf(path, topic="/tf", stats=None):
     """All transforms of `topic`, in bag order: list of dicts with keys
-    recv_time, stamp, frame_id, child_frame_id, pose (np.ndarray[7])."""
+    recv_time, stamp, frame_id, child_frame_id, pose (np.ndarray[7]).  stats (a dict) receives
+    messages = the number of TFMessage records decoded."""
     buf = open(path, "rb").read()
     if not buf.startswith(b"#ROSBAG V2.0\n"):
         raise ValueError("not a rosbag v2 file: %s" % path)
@@ -84,6 +121,8 @@ def read_tf(path, topic="/tf"):
             if tp == topic and ty == "tf2_msgs/TFMessage":
                 sec, nsec = struct.unpack("<II", fields["time"])
                 recv = float(sec) + 1e-9 * float(nsec)
+                if stats is not None:
+                    stats["messages"] = stats.get("messages", 0) + 1
                 for stamp, frame, child, pose in parse_tf_message(data):
                     out.append(dict(recv_time=recv, stamp=stamp, frame_id=frame, child_frame_id=child, pose=pose))
         elif op == OP_CHUNK:

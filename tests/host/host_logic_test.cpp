@@ -113,8 +113,48 @@ static void check_id_table() {
   std::printf("id table ok (%zu live ids after the random schedule)\n", t.size());
 }
 
+// parameter-class rows (te_layout.hpp qr_*): every entry the kernels read has exactly one word, the separable rows hold
+// only in-group entries, contiguously
+template <class M>
+static void check_qr_rows(const char* name) {
+  for (int sep = 0; sep < 2; ++sep) {
+    const int n = M::N, m = M::K, words = qr_words(M::TYPE, sep != 0);
+    std::vector<int> hits((size_t)words, 0);
+    int in_group_q = 0, in_group_r = 0;
+    for (int r = 0; r < n; ++r)
+      for (int c = 0; c < n; ++c) {
+        const int w = qr_q_word(M::TYPE, sep != 0, r, c);
+        const bool same = group_of(M::TYPE, r) == group_of(M::TYPE, c);
+        if (sep && !same) { CHECK(w == -1); continue; }
+        CHECK(w >= 0 && w < qr_q_count(M::TYPE, sep != 0));
+        ++hits[(size_t)w];
+        in_group_q += same ? 1 : 0;
+      }
+    for (int r = 0; r < m; ++r)
+      for (int c = 0; c < m; ++c) {
+        const int w = qr_r_word(M::TYPE, sep != 0, r, c);
+        const bool same = group_of(M::TYPE, r) == group_of(M::TYPE, c);
+        if (sep && !same) { CHECK(w == -1); continue; }
+        CHECK(w >= qr_q_count(M::TYPE, sep != 0) && w < words);
+        ++hits[(size_t)w];
+        in_group_r += same ? 1 : 0;
+      }
+    for (int w = 0; w < words; ++w) CHECK(hits[(size_t)w] == 1);
+    if (sep) CHECK(words == in_group_q + in_group_r);
+    else CHECK(words == n * n + m * m);
+  }
+  std::printf("qr rows ok: %s (%d dense words, %d separable)\n", name, qr_words(M::TYPE, false), qr_words(M::TYPE, true));
+}
+
 int main(int argc, char** argv) {
   check_id_table();
+  check_qr_rows<ModelUV>("UV");
+  check_qr_rows<ModelUA>("UA");
+  check_qr_rows<ModelAV>("AV");
+  check_qr_rows<ModelAR>("AR");
+  CHECK(qr_words(UNIFORM_VELOCITY, true) == 15 && qr_words(UNIFORM_ACCELERATION, true) == 30);
+  CHECK(qr_words(ANGULAR_VELOCITIES, true) == 60 && qr_words(ANGULAR_RATES, true) == 60);
+  CHECK((Cfg<ModelAR, double, 1, LAYOUT_SEPARABLE_PACKED>::QR_WORDS == 60) && (Cfg<ModelAR, double, 6, LAYOUT_FULL>::QR_WORDS == 360));
   check_layout<ModelUV, double, 1, LAYOUT_FULL>("UV f64 G1 full");
   check_layout<ModelUV, double, 3, LAYOUT_FULL>("UV f64 G3 full");
   check_layout<ModelUV, float, 3, LAYOUT_FULL>("UV f32 G3 full");

@@ -33,6 +33,21 @@ def test_reader_reproduces_the_fixture():
         np.testing.assert_array_equal(a["pose"], b["pose"])
 
 
+def test_reader_agrees_with_the_bags_own_index():
+    """Independent of the reader's walk over the chunks: the bag's INDEX section (written by the ROS recorder) declares how
+    many messages the /tf connection holds; the reader must have decoded exactly that many, each TFMessage consumed to its
+    last byte (parse_tf_message raises otherwise).  Stored in the fixture when it was made; re-derived here when the
+    reference tree is present."""
+    a = np.load(FIX)
+    assert int(a["tf_messages_declared_by_the_bag_index"]) == int(a["tf_messages_decoded"]) == 572
+    assert int(a["bag_conn_count"]) == 1 and int(a["bag_chunk_count"]) == 1
+    if os.path.exists(BAG):
+        declared, conns, chunks = rosbag_tf.declared_counts(BAG)
+        stats = {}
+        rosbag_tf.read_tf(BAG, stats=stats)
+        assert declared == {"/tf": stats["messages"]} and (conns, chunks) == (1, 1)
+
+
 def test_fixture_contents_and_cpu_replay(models):
     fx = load_fixture()
     names = sorted({t["child_frame_id"] for t in fx})
