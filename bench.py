@@ -232,8 +232,9 @@ def summarize(name, desc, models, dtype, batches, kernels, n_total, world, steps
                 cycles_per_s=n_total * world * steps / elapsed, device_ms_per_step=dev_ms / steps,
                 algorithmic_bytes_per_cycle=alg / n_total, algorithmic_bytes_per_step=alg,
                 achieved_gbs=alg / (dev_ms * 1e-3 / steps) / 1e9, state_bytes=int(state),
-                residency="HBM-bound (state beyond the 256 MB Infinity Cache)" if state > 4 * L3_BYTES else
-                          ("L3-assisted (state fits or nearly fits the 256 MB Infinity Cache)" if state > (32 << 20) else "L2/L3-resident, launch-bound"),
+                residency=("HBM-bound (state > 1 GB, 4 x the Infinity Cache)" if state > 4 * L3_BYTES else
+                           "L3-assisted: state = %.1f x the 256 MB Infinity Cache (zig-zag traversal reuses the part touched last)" % (state / L3_BYTES) if state > L3_BYTES else
+                           "L3-assisted: state fits the 256 MB Infinity Cache" if state > (32 << 20) else "L2/L3-resident, launch-bound"),
                 launch_mode=launch_mode)
 
 

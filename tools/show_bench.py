@@ -25,4 +25,4 @@ for e in d.get("extra", []):
     else:
         print("  %-16s %-3s %9d  %9.4g c/s  %8.4f ms  %6.0f GB/s  frac %.3f  %-12s %s" % (
             e["name"], e["dtype"], e["targets_per_gpu"], e["cycles_per_s"], e["ms_per_step"], e["achieved_gbs"], e["roofline_frac"],
-            e["residency"][:11], e["layout"][:28]))
+            e["residency"][:12], e["layout"][:28]))
