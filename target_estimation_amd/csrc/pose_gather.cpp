@@ -131,9 +131,11 @@ void PoseComm::wait() {
   if (!in_flight_) return;
   TE_HIP_CHECK(hipEventSynchronize(done_));
   in_flight_ = false;
+  timed_ = true;
 }
 
 float PoseComm::last_ms() {
+  if (!timed_ || in_flight_) return 0.f;   // no finished gather yet: the events were never recorded
   float ms = 0.f;
   TE_HIP_CHECK(hipEventElapsedTime(&ms, start_, done_));
   return ms;

@@ -46,7 +46,7 @@ class PoseComm {
   int rank_, world_;
   hipStream_t stream_ = nullptr;
   hipEvent_t ready_ = nullptr, start_ = nullptr, done_ = nullptr;
-  bool in_flight_ = false;
+  bool in_flight_ = false, timed_ = false;
   double* send_ = nullptr;
   long send_cap_ = 0;
 };

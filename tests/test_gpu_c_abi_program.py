@@ -29,6 +29,25 @@ def test_plain_c_caller_of_the_ten_symbols(tmp_path):
     assert "Target(8) does not exist!" in out.stdout
 
 
+def test_plain_c_caller_of_the_batch_extension(tmp_path):
+    """tests/c_abi/batch_ext_test.c: gcc -std=c99 against target_batch_c.h -- parameter classes, by-id calls in random order
+    (device-resolved), unknown ids, getters in the caller's order, erase, and the gather's argument validation."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    libdir = os.path.join(ROOT, "target_estimation_amd", "lib")
+    exe = str(tmp_path / "batch_ext_test")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-Werror",
+                           "-I", os.path.join(ROOT, "include", "target_estimation_amd"),
+                           os.path.join(ROOT, "tests", "c_abi", "batch_ext_test.c"), "-o", exe,
+                           "-L", libdir, "-ltarget_estimation_amd", "-lm", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe, model_path("uniform_acceleration")], capture_output=True, text=True, timeout=300)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "batch extension test ok" in out.stdout
+
+
 def test_cpp_example_of_the_batch_api(tmp_path):
     """examples/batched_replay.cpp: the device-resident batch API driven from plain C++ (hipcc, no Python)."""
     import torch
