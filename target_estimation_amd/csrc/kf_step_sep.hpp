@@ -125,6 +125,7 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
   const T* Qm = a.qr;
   if constexpr (PERQR) {
     if (valid) Qm = a.qr + (long)a.cls[slot_of] * C::QR_WORDS;
+    if constexpr ((C::QR_WORDS * sizeof(T)) % 16 == 0) Qm = static_cast<const T*>(__builtin_assume_aligned(Qm, 16));   // rows are whole 16-byte chunks: wide loads
   }
   // the [p v (a)] chains.  Linear models: K of them, rows {i, i+K, i+2K}.  EKF: x, y, z with rows
   // {i, i+6} (position, velocity), plus the 6-state attitude group (rows 3..5, 9..11).

@@ -126,7 +126,7 @@ static void check_qr_rows(const char* name) {
         const int w = qr_q_word(M::TYPE, sep != 0, r, c);
         const bool same = group_of(M::TYPE, r) == group_of(M::TYPE, c);
         if (sep && !same) { CHECK(w == -1); continue; }
-        CHECK(w >= 0 && w < qr_q_count(M::TYPE, sep != 0));
+        CHECK(w >= 0 && w < words);
         ++hits[(size_t)w];
         in_group_q += same ? 1 : 0;
       }
@@ -135,7 +135,7 @@ static void check_qr_rows(const char* name) {
         const int w = qr_r_word(M::TYPE, sep != 0, r, c);
         const bool same = group_of(M::TYPE, r) == group_of(M::TYPE, c);
         if (sep && !same) { CHECK(w == -1); continue; }
-        CHECK(w >= qr_q_count(M::TYPE, sep != 0) && w < words);
+        CHECK(w >= 0 && w < words);
         ++hits[(size_t)w];
         in_group_r += same ? 1 : 0;
       }
@@ -154,6 +154,10 @@ int main(int argc, char** argv) {
   check_qr_rows<ModelAR>("AR");
   CHECK(qr_words(UNIFORM_VELOCITY, true) == 15 && qr_words(UNIFORM_ACCELERATION, true) == 30);
   CHECK(qr_words(ANGULAR_VELOCITIES, true) == 60 && qr_words(ANGULAR_RATES, true) == 60);
+  // a chain's Q block and its R entry are one contiguous run (group-major order)
+  CHECK(qr_q_word(ANGULAR_RATES, true, 0, 0) == 0 && qr_q_word(ANGULAR_RATES, true, 12, 12) == 8 && qr_r_word(ANGULAR_RATES, true, 0, 0) == 9);
+  CHECK(qr_q_word(ANGULAR_RATES, true, 1, 1) == 10 && qr_r_word(ANGULAR_RATES, true, 5, 5) == 59);
+  CHECK(qr_q_word(ANGULAR_VELOCITIES, true, 3, 3) == 15 && qr_r_word(ANGULAR_VELOCITIES, true, 3, 3) == 51 && qr_r_word(ANGULAR_VELOCITIES, true, 5, 5) == 59);
   CHECK((Cfg<ModelAR, double, 1, LAYOUT_SEPARABLE_PACKED>::QR_WORDS == 60) && (Cfg<ModelAR, double, 6, LAYOUT_FULL>::QR_WORDS == 360));
   check_layout<ModelUV, double, 1, LAYOUT_FULL>("UV f64 G1 full");
   check_layout<ModelUV, double, 3, LAYOUT_FULL>("UV f64 G3 full");
