@@ -1,5 +1,5 @@
 #!/bin/bash
-# gpu tests + the driver-style bench line
+# gpu tests + the driver-style bench line: gpurun -- bash tools/gpu_check.sh <tag>   (outputs under gpurun_out/<tag>)
 set -o pipefail
 OUT=$PWD/gpurun_out/${1:-r2b}
 mkdir -p $OUT
