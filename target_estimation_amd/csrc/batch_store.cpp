@@ -326,7 +326,11 @@ void Batch::step_sequence(long n_ticks, double dt, const void* meas_base, long t
       GraphEntry e{n_ticks, tick_stride, ld, has_stride, n_, dt, meas_base, has_base, d_rec_, nullptr, nullptr, ring_ticks};
       TE_HIP_CHECK(hipStreamBeginCapture(cap_stream_, hipStreamCaptureModeThreadLocal));
       try {
-        for (long s = 0; s < n_ticks; ++s) ops_->step(params(s), cap_stream_);
+        for (long s = 0; s < n_ticks; ++s) {
+          ops_->step(params(s), cap_stream_);
+          if (s == 0 && std::getenv("TE_TEST_FAIL_IN_CAPTURE"))   // test hook: a launch that throws between Begin and EndCapture
+            throw std::runtime_error("target_estimation_amd: injected failure inside stream capture");
+        }
         TE_HIP_CHECK(hipGetLastError());
       } catch (...) {
         hipGraph_t broken = nullptr;

@@ -997,6 +997,7 @@ void TargetManager::stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpe
           set_deps(none);                                  // a new chain: no predecessor
           const bool zz = batches_[b]->state_bytes() >= Batch::zigzag_min_bytes();
           for (long s = 0; s < n_ticks; ++s) batches_[b]->enqueue_tick(cap, s, dt, specs[b], query, org, radius, zz && (s & 1) != 0);
+          if (std::getenv("TE_TEST_FAIL_IN_CAPTURE")) throw std::runtime_error("target_estimation_amd: injected failure inside stream capture");
           const Nodes tail = captured();
           leaves.insert(leaves.end(), tail.begin(), tail.end());
         }

@@ -519,3 +519,42 @@ def test_host_fed_soa_step_equals_device_step(models, name, dtype):
     np.testing.assert_array_equal(res[0][0], res[1][0])
     np.testing.assert_array_equal(res[0][1], res[1][1])
     assert res[0][2] == res[1][2]
+
+
+def test_a_failure_inside_stream_capture_leaves_no_capture_behind(models, monkeypatch):
+    """Round-1 finding: a launch that throws between hipStreamBeginCapture and EndCapture left the capture stream in
+    capture mode.  Both recording sites (one batch: target_batch_step_sequence; all batches:
+    target_manager_step_sequence_all) now end and destroy the broken capture before reporting.  The failure is injected
+    (TE_TEST_FAIL_IN_CAPTURE); afterwards the same call must record, replay and give the bits of plain single steps."""
+    name, dt, N, ticks = "uniform_acceleration", 0.004, 500, 6
+    m = models[name]
+    p0, meas = synth_stream(name, N, ticks, seed=9)
+    ids = np.arange(N, dtype=np.uint32)
+
+    def fresh():
+        mgr = te.TargetManager(model_path(name), dtype="f64")
+        mgr.set_stream(torch.cuda.current_stream().cuda_stream)
+        mgr.init_batch(ids, dt, 0.0, p0)
+        return mgr, mgr.batches()[0]
+
+    ref, rb = fresh()
+    for s in range(ticks):
+        rb.step(dt, to_soa(meas[s], rb))
+    want = ref.get_state_batch(ids)
+    mgr, b = fresh()
+    seq = torch.stack([to_soa(meas[s], b) for s in range(ticks)])
+    monkeypatch.setenv("TE_TEST_FAIL_IN_CAPTURE", "1")
+    with pytest.raises(RuntimeError, match="injected failure"):
+        b.step_sequence(dt, seq, use_graph=True)
+    with pytest.raises(RuntimeError, match="injected failure"):
+        mgr.step_sequence_all(dt, [seq], use_graph=1)
+    monkeypatch.delenv("TE_TEST_FAIL_IN_CAPTURE")
+    # nothing was stepped, nothing is stuck: record + replay now works on both paths
+    assert mgr.getTime(0) == pytest.approx(0.0)
+    b.step_sequence(dt, seq[:3], use_graph=True)
+    mgr.step_sequence_all(dt, [seq[3:]], use_graph=1)
+    got = mgr.get_state_batch(ids)
+    np.testing.assert_array_equal(got[0], want[0])
+    np.testing.assert_array_equal(got[1], want[1])
+    torch.cuda.synchronize()
+    ref.close(); mgr.close()
