@@ -36,7 +36,7 @@ def main():
         b = json.loads(line)
         print("# bench line of the same process: value %.4g %s, ms_per_step %.4f, roofline.kernel %s avg_launch_ms %.4f (HIP events) -- compare with the"
               % (b["value"], b["unit"], b["ms_per_step"], b["roofline"]["kernel"], b["roofline"]["avg_launch_ms"]))
-        print("# rocprofv3 average of that kernel at grid %d above" % (-(-b["roofline"]["units_per_launch"] // 64) * 64))
+        print("# rocprofv3 average of that kernel at grid %d above" % (-(-b["roofline"]["units_per_launch"] // 256) * 256))
         for k in b["roofline"]["kernels"]:
             print("#   %-44s units %8d  avg_launch_ms (events) %.4f" % (k["kernel"], k["units_per_launch"], k["avg_launch_ms"]))
 
