@@ -9,6 +9,7 @@ const Ops* get_ops_av(int dtype, int g) {
     switch (g) {
       case 3: return OpsImpl<ModelAV, double, 3>::get();
       case 6: return OpsImpl<ModelAV, double, 6>::get();
+      case 101: return OpsImpl<ModelAV, double, 1, LAYOUT_PACKED>::get();  // symmetric-packed P, thread per target (ekf_sym.hpp)
       case 103: return OpsImpl<ModelAV, double, 3, LAYOUT_PACKED>::get();  // symmetric-packed P, 3 lanes per target
       case 106: return OpsImpl<ModelAV, double, 6, LAYOUT_PACKED>::get();  // symmetric-packed P, 6 lanes per target
       case 201: return OpsImpl<ModelAV, double, 1, LAYOUT_SEPARABLE>::get();  // axis-separable

@@ -38,7 +38,8 @@ struct OpsImpl {
     // Two temporally fused instantiations do not fit the register file and would spill to scratch (profiles/
     // r02_kernel_resources.txt: 228 / 116 B per lane): for them a fused request is served tick by tick -- same results.
     constexpr bool kFusedSpills = (M::TYPE == ANGULAR_RATES && sizeof(T) == 8 && G == 3 && LAYOUT == LAYOUT_PACKED) ||
-                                  (M::TYPE == ANGULAR_VELOCITIES && sizeof(T) == 4 && G == 1 && LAYOUT == LAYOUT_FULL);
+                                  (M::TYPE == ANGULAR_VELOCITIES && sizeof(T) == 4 && G == 1 && LAYOUT == LAYOUT_FULL) ||
+                                  (M::TYPE == ANGULAR_VELOCITIES && sizeof(T) == 8 && G == 1 && LAYOUT == LAYOUT_PACKED);
     if (kFusedSpills && p.n_ticks > 1) {
       StepParams q = p;
       q.n_ticks = 1;

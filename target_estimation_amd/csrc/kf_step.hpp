@@ -23,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "ekf_sym.hpp"
 #include "kf_aux.hpp"
 #include "te_device_math.hpp"
 #include "te_layout.hpp"
@@ -117,10 +118,18 @@ template <typename T> __device__ __forceinline__ T sel3(int c, T a, T b, T d) { 
 // sphere_query); with G > 1 the state is first collected from the G lanes through the wave's LDS scratch.
 // PERQR: every target reads the Q and R of its own parameter class (TargetManager::init takes Q, R per target,
 // target_manager.hpp:85-87) from a table in HBM (L2-resident for 10^3 classes) instead of the one pair staged in LDS.
+// minimum wavefronts per SIMD the register allocation must leave room for: 2 for the thread-per-target symmetric EKF in fp32
+// (ekf_sym.hpp; unconstrained the scheduler stretches live ranges to ~300 registers), 1 (no constraint) elsewhere
+template <class M, typename T, int G, int LAYOUT>
+constexpr int step_min_waves() { return 1; }
+
 template <class M, typename T, int G, int LAYOUT, bool INDEXED, bool FUSED = false, bool QUERY = false, bool PERQR = false>
-__global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kernel(const StepArgs<T> a) {
+__global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64), (step_min_waves<M, T, G, LAYOUT>()))
+kf_step_kernel(const StepArgs<T> a) {
   using C = Cfg<M, T, G, LAYOUT>;
   constexpr bool PK = C::PK;
+  // the EKF on a symmetric-packed covariance, thread per target: works on the triangle in place (ekf_sym.hpp)
+  constexpr bool EKF_SYM = M::EKF && PK && G == 1;
   static_assert(!(QUERY && (INDEXED || FUSED)), "the fused query is for dense single-tick launches");
   static_assert(!(PERQR && (FUSED || QUERY)), "per-class Q/R: single-tick launches without the fused query");
   static_assert(!C::SEP, "the separable layout has its own kernel (kf_step_sep.hpp)");
@@ -216,7 +225,9 @@ __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kern
         if (c >= r) EXP_(tri_base[q] + c) = rec[q * N + c];
     }
   };
-  if constexpr (PK && G == 1) {
+  if constexpr (EKF_SYM) {
+    // no register image: the step works on `mem` directly
+  } else if constexpr (PK && G == 1) {
 #pragma unroll
     for (int r = 0; r < N; ++r)
 #pragma unroll
@@ -289,6 +300,9 @@ __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kern
     }
   }
 
+  if constexpr (EKF_SYM) {
+    ekf_sym_tick<C, T>(mem, sQ, sR, dt, has, ymeas_own, mrpy);
+  } else {
   // ------------------------------------------------------------------ predict
   if constexpr (!M::EKF) {
     const T hdt = (T)0.5 * dt * dt;  // angular_rates.cpp:114 / uniform_acceleration.cpp:98
@@ -595,7 +609,8 @@ __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kern
     }
   }
 
-  if constexpr (FUSED && PK) {
+  }  // !EKF_SYM
+  if constexpr (FUSED && PK && !EKF_SYM) {
     // a packed batch re-symmetrises P every tick (store upper triangle, reload mirrored)
     if constexpr (G == 1) {
 #pragma unroll
@@ -624,8 +639,8 @@ __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kern
     for (int w = 0; w < RPL + C::UW; ++w) mem[C::X_OFF + w] = rec[RPL * N + w];
   }
   if (valid) {
-    if constexpr (PK && G > 1) {
-      // mem was filled above
+    if constexpr ((PK && G > 1) || EKF_SYM) {
+      // mem was filled above / is what the step worked on
     } else if constexpr (PK) {
 #pragma unroll
       for (int r = 0; r < N; ++r)
@@ -650,7 +665,10 @@ __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64)) kf_step_kern
   }
   if constexpr (QUERY) {
     T xq[N];
-    if constexpr (G == 1) {
+    if constexpr (EKF_SYM) {
+#pragma unroll
+      for (int r = 0; r < N; ++r) xq[r] = mem[C::X_OFF + r];
+    } else if constexpr (G == 1) {
 #pragma unroll
       for (int r = 0; r < N; ++r) xq[r] = X_(r);
     } else {

@@ -210,14 +210,16 @@ int TargetManager::chooseLayout(int type, const double* Q, const double* R, cons
     const bool sym = all_symmetric(type, Q, R, P0, n_P0);
     if (sep) return sym ? kSeparablePacked : kSeparable;
     if (!sym) return 0;   // general matrices: dense kernel, full P, tuned lanes per target
-    // coupled but symmetric: dense kernel on the upper triangle (100 + lanes per target).  Per (model, precision) the
-    // fastest packed form at 10^6 targets, among those that run at >= 2 wavefronts per SIMD where one exists within a
-    // ten percent (profiles/r02_layout_sweep.txt, profiles/r02_kernel_resources.txt).  One pick stays at one wavefront
-    // per SIMD: angular_rates fp64 (103: 714 us per 10^6-target tick; its two-wave alternatives, 106 and the full-P
-    // G = 6 kernel, take 1034 and 1102 us -- the LDS transposition of the triangle, not occupancy, is what they wait for).
+    // coupled but symmetric: dense kernel on the upper triangle (100 + lanes per target): per (model, precision) the
+    // fastest packed form at 10^6 targets (profiles/r02_layout_sweep.txt, profiles/r02_kernel_resources.txt).
+    //   angular_velocities: 101 = thread per target on the triangle in place (ekf_sym.hpp): 309 us fp64 / 190 us fp32 per
+    //     10^6-target tick against 493 / 212 us for the best lanes-per-target form (106 / 103);
+    //   angular_rates: 103 (714 us fp64; 106 and the full-P G = 6 kernel take 1034 and 1102 us).
+    // Three of these picks run at one wavefront per SIMD (AV 101 both precisions, AR fp64 103): they are the fastest forms
+    // measured; their two-wave alternatives lose 10-60 %.
     switch (type) {
       case ANGULAR_RATES: return 103;
-      case ANGULAR_VELOCITIES: return dtype_ == F32 ? 103 : 106;
+      case ANGULAR_VELOCITIES: return 101;
       case UNIFORM_ACCELERATION: return dtype_ == F32 ? 103 : 101;
       default: return 101;
     }

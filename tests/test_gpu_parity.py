@@ -27,7 +27,7 @@ TOL = {"f64": dict(x_atol=1e-10, x_rtol=1e-10, P_rel=1e-9, out_atol=1e-9),
 LANES = {"uniform_velocity": {"f64": [0, 1, 3, 101, 103, 201, 301], "f32": [1, 3, 101, 103, 201, 301]},
          "uniform_acceleration": {"f64": [0, 1, 3, 101, 103, 201, 301], "f32": [1, 3, 101, 103, 201, 301]},
          "angular_rates": {"f64": [0, 3, 6, 103, 106, 201, 301], "f32": [2, 3, 6, 102, 103, 106, 201, 301]},
-         "angular_velocities": {"f64": [0, 3, 6, 103, 106, 201, 301], "f32": [1, 3, 6, 101, 103, 106, 201, 301]}}
+         "angular_velocities": {"f64": [0, 3, 6, 101, 103, 106, 201, 301], "f32": [1, 3, 6, 101, 103, 106, 201, 301]}}
 LAYOUT_OF = {0: "axis_separable_packed", 101: "symmetric_packed", 102: "symmetric_packed", 103: "symmetric_packed",
              106: "symmetric_packed", 201: "axis_separable", 301: "axis_separable_packed"}
 CASES = [(m, d, g) for m in HARNESS_ORDER for d in ("f64", "f32") for g in LANES[m][d]]

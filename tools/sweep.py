@@ -12,7 +12,7 @@ import bench  # noqa: E402
 LANES = {"uniform_velocity": {"f64": [1, 3, 101, 103, 201, 301], "f32": [1, 3, 101, 103, 201, 301]},
          "uniform_acceleration": {"f64": [1, 3, 101, 103, 201, 301], "f32": [1, 3, 101, 103, 201, 301]},
          "angular_rates": {"f64": [3, 6, 103, 106, 201, 301], "f32": [2, 3, 6, 102, 103, 106, 201, 301]},
-         "angular_velocities": {"f64": [3, 6, 103, 106, 201, 301], "f32": [1, 3, 6, 101, 103, 106, 201, 301]}}
+         "angular_velocities": {"f64": [3, 6, 101, 103, 106, 201, 301], "f32": [1, 3, 6, 101, 103, 106, 201, 301]}}
 
 
 def main():
