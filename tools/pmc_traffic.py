@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--workloads", default=",".join([bench.HEADLINE] + bench.DEFAULT_EXTRA.split(",")))
     ap.add_argument("--steps", type=int, default=8)
     args = ap.parse_args()
+    args.out = os.path.abspath(args.out)   # rocprofv3 runs with cwd = /tmp
     os.makedirs(args.out, exist_ok=True)
     result, failures = {}, []
     for wl in [w for w in args.workloads.split(",") if w]:
