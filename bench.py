@@ -43,7 +43,7 @@ MODEL_STRUCT = {"uniform_velocity": "ModelUV", "uniform_acceleration": "ModelUA"
 # axis-separable layout with full group blocks, *_full / *_packed the dense kernel (what general matrices get).
 # None = "whatever the library picks for coupled matrices" (resolved in run_workload through forced_general).
 TUNED_LANES = {"cfg2_full": 3, "uv1m_full": 1, "ua1m_full": 3, "ar1m_full": 6, "av1m_full": 3, "uv1m_packed": 101,
-               "ar1m_packed": 103, "av1m_packed": 101, "ar1m64_packed": 103, "av1m64_packed": 101, "ar1m64_full": 6, "av1m64_full": 6,
+               "ar1m_packed": 103, "av1m_packed": 101, "ar1m64_packed": 106, "av1m64_packed": 101, "ar1m64_full": 6, "av1m64_full": 6,
                "uv1m_s201": 201, "ua1m_s201": 201, "av1m_s201": 201, "ar1m_s201": 201}
 
 GRAPH_TICKS = 64     # ticks per recorded hipGraph block (small, launch-bound batches)

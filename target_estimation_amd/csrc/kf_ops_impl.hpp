@@ -35,11 +35,12 @@ struct OpsImpl {
     const int wpb_dense = waves <= small_grid ? 1 : C::WPB;
     const unsigned blocks = (unsigned)((waves + wpb_dense - 1) / wpb_dense);
     if (p.n_ticks > 1 && p.idx) throw std::runtime_error("target_estimation_amd: fused multi-tick launches are dense only");
-    // Two temporally fused instantiations do not fit the register file and would spill to scratch (profiles/
-    // r02_kernel_resources.txt: 228 / 116 B per lane): for them a fused request is served tick by tick -- same results.
+    // A few temporally fused instantiations do not fit the register file and would spill hundreds of bytes per lane to
+    // scratch (228 / 116 / 340 / 352 B): for them a fused request is served tick by tick -- same results.
     constexpr bool kFusedSpills = (M::TYPE == ANGULAR_RATES && sizeof(T) == 8 && G == 3 && LAYOUT == LAYOUT_PACKED) ||
                                   (M::TYPE == ANGULAR_VELOCITIES && sizeof(T) == 4 && G == 1 && LAYOUT == LAYOUT_FULL) ||
-                                  (M::TYPE == ANGULAR_VELOCITIES && sizeof(T) == 8 && G == 1 && LAYOUT == LAYOUT_PACKED);
+                                  (M::TYPE == ANGULAR_VELOCITIES && sizeof(T) == 8 && G == 1 && LAYOUT == LAYOUT_PACKED) ||
+                                  (M::TYPE == ANGULAR_RATES && sizeof(T) == 8 && G == 6 && LAYOUT == LAYOUT_PACKED);
     if (kFusedSpills && p.n_ticks > 1) {
       StepParams q = p;
       q.n_ticks = 1;

@@ -118,10 +118,12 @@ template <typename T> __device__ __forceinline__ T sel3(int c, T a, T b, T d) { 
 // sphere_query); with G > 1 the state is first collected from the G lanes through the wave's LDS scratch.
 // PERQR: every target reads the Q and R of its own parameter class (TargetManager::init takes Q, R per target,
 // target_manager.hpp:85-87) from a table in HBM (L2-resident for 10^3 classes) instead of the one pair staged in LDS.
-// minimum wavefronts per SIMD the register allocation must leave room for: 2 for the thread-per-target symmetric EKF in fp32
-// (ekf_sym.hpp; unconstrained the scheduler stretches live ranges to ~300 registers), 1 (no constraint) elsewhere
+// Minimum wavefronts per SIMD the register allocation must leave room for.  1 = no constraint, except angular_rates fp64 on
+// the upper triangle with 6 lanes per target: unconstrained it takes 262 registers (one wavefront per SIMD, 1034 us per
+// 10^6-target tick); held to 256 it parks four doubles in scratch (32-44 B per lane) and runs two wavefronts: 647 us.
+// (The same constraint on the thread-per-target symmetric EKF in fp32 bought nothing: 188 vs 190 us, 252 B of scratch.)
 template <class M, typename T, int G, int LAYOUT>
-constexpr int step_min_waves() { return 1; }
+constexpr int step_min_waves() { return (M::TYPE == ANGULAR_RATES && LAYOUT == LAYOUT_PACKED && G == 6 && sizeof(T) == 8) ? 2 : 1; }
 
 template <class M, typename T, int G, int LAYOUT, bool INDEXED, bool FUSED = false, bool QUERY = false, bool PERQR = false>
 __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64), (step_min_waves<M, T, G, LAYOUT>()))

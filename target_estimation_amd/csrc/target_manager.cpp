@@ -214,11 +214,11 @@ int TargetManager::chooseLayout(int type, const double* Q, const double* R, cons
     // fastest packed form at 10^6 targets (profiles/r02_layout_sweep.txt, profiles/r02_kernel_resources.txt).
     //   angular_velocities: 101 = thread per target on the triangle in place (ekf_sym.hpp): 309 us fp64 / 190 us fp32 per
     //     10^6-target tick against 493 / 212 us for the best lanes-per-target form (106 / 103);
-    //   angular_rates: 103 (714 us fp64; 106 and the full-P G = 6 kernel take 1034 and 1102 us).
-    // Three of these picks run at one wavefront per SIMD (AV 101 both precisions, AR fp64 103): they are the fastest forms
-    // measured; their two-wave alternatives lose 10-60 %.
+    //   angular_rates: fp64 106 held to two wavefronts per SIMD (kf_step.hpp step_min_waves: 647 us; 103 takes 714 us at
+    //     one wavefront), fp32 103 (299 us).
+    // The AV picks run at one wavefront per SIMD: they are the fastest forms measured, their two-wave alternatives lose 10-60 %.
     switch (type) {
-      case ANGULAR_RATES: return 103;
+      case ANGULAR_RATES: return dtype_ == F32 ? 103 : 106;
       case ANGULAR_VELOCITIES: return 101;
       case UNIFORM_ACCELERATION: return dtype_ == F32 ? 103 : 101;
       default: return 101;
