@@ -13,11 +13,15 @@
 //               (r < 6, c < 6, both).  Order: top-left block, then top-right, then the bottom-right (+Q only), so that
 //               every read still sees the prior covariance.
 //     update  : W = P^-[:,0:6] is a VIEW of the triangle (W[c][l] = P^-[l][c]); the gain U = W S^-1 is formed and consumed in
-//               two halves of 36 registers; P^+[r][c] = P^-[r][c] - sum_l U[r][l] W[c][l] for r <= c, bottom-right first,
+//               pieces (rows 6..8, 9..11: 18 registers each; rows 0..5: 36); P^+[r][c] = P^-[r][c] - sum_l U[r][l] W[c][l] for r <= c, bottom-right first,
 //               then the top-right and the top-left block column by column (six temporaries; ascending in the top-left,
 //               so that every read still sees the prior block).
 // The products are the reference's, summed k / l ascending with fma; what differs from the full-P kernel is the association
 // A P A^T = P + NP + PN^T + NPN^T (rounding level, like every packed layout; stated tolerance unchanged).
+// Register budget (fp32): 93 words of record + S^-1 (36) + a piece of the gain (18 / 36) + innovation (6) = 160 allocated, three
+// wavefronts per SIMD -- given that (a) the record words are detached from their 16-byte load / store tuples
+// (kf_step.hpp opaque_copy) and (b) the SLP vectorizer is off for this translation unit (kf_model_av_sym.hip): it hoists
+// blocks across the sched_barriers below to build v_pk_fma_f32 pairs and costs 120 registers.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -161,34 +165,37 @@ __device__ __forceinline__ void ekf_sym_tick(T* mem, const T* Qm, const T* Rm, c
     US_(c) = y;
     nu[3 + c] = y - XS_(3 + c);
   }
-  // The gain U = P^-[:,0:6] S^-1 (12 x 6) is formed and consumed in two halves of 36 registers: rows 6..11 first (they
+  // The gain U = P^-[:,0:6] S^-1 (12 x 6) is formed and consumed in pieces: rows 6..8 and 9..11 first (18 registers each; they
   // update the bottom-right block, which reads the top-right PRIOR entries), then rows 0..5 (top-right, then top-left).
   // W[c][l] = P^-[l][c] is a view of the triangle.
-  {
-    T U[K][K];   // rows 6..11 of the gain
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    constexpr int H = K / 2;
+    T U[H][K];   // rows 6 + 3 h .. 8 + 3 h of the gain
 #pragma unroll
     for (int l = 0; l < K; ++l)
 #pragma unroll
       for (int c = 0; c < K; ++c)
 #pragma unroll
-        for (int r = 0; r < K; ++r) U[r][l] = (c == 0) ? PS_(K + r, 0) * S[0][l] : F::fma(PS_(K + r, c), S[c][l], U[r][l]);
+        for (int r = 0; r < H; ++r) U[r][l] = (c == 0) ? PS_(K + H * h + r, 0) * S[0][l] : F::fma(PS_(K + H * h + r, c), S[c][l], U[r][l]);
 #pragma unroll
-    for (int r = 0; r < K; ++r) {
+    for (int r = 0; r < H; ++r) {
       T acc = U[r][0] * nu[0];
 #pragma unroll
       for (int l = 1; l < K; ++l) acc = F::fma(U[r][l], nu[l], acc);
-      XS_(K + r) += acc;
+      XS_(K + H * h + r) += acc;
     }
     // (a) bottom-right (6 <= r <= c)
 #pragma unroll
-    for (int r = K; r < N; ++r)
+    for (int r = 0; r < H; ++r)
 #pragma unroll
-      for (int c = r; c < N; ++c) {
-        T acc = U[r - K][0] * PS_(0, c);
+      for (int c = K + H * h + r; c < N; ++c) {
+        T acc = U[r][0] * PS_(0, c);
 #pragma unroll
-        for (int l = 1; l < K; ++l) acc = F::fma(U[r - K][l], PS_(l, c), acc);
-        PS_(r, c) = PS_(r, c) - acc;
+        for (int l = 1; l < K; ++l) acc = F::fma(U[r][l], PS_(l, c), acc);
+        PS_(K + H * h + r, c) = PS_(K + H * h + r, c) - acc;
       }
+    __builtin_amdgcn_sched_barrier(0);
   }
   __builtin_amdgcn_sched_barrier(0);
   {

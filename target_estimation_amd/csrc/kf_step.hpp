@@ -79,6 +79,13 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// A copy the register coalescer cannot see through.  The 16-byte loads and stores of a record define and use 4-register
+// tuples; a value that is updated in place would have to be allocated inside the tuple it was loaded into AND inside the
+// tuple it is stored from, for its whole life, and the allocator answers by keeping both images.  Copying every word out of
+// its load tuple (and into its store tuple) with an opaque move lets the words live and die one by one.
+__device__ __forceinline__ float opaque_copy(float v) { float o; asm("v_mov_b32 %0, %1" : "=v"(o) : "v"(v)); return o; }
+__device__ __forceinline__ double opaque_copy(double v) { double o; asm("v_mov_b64 %0, %1" : "=v"(o) : "v"(v)); return o; }
+
 template <class C, typename T>
 __device__ __forceinline__ void load_record(const char* tb, int lane, T* rec) {
   using V = typename Vec16<T>::type;
@@ -95,15 +102,21 @@ __device__ __forceinline__ void load_record(const char* tb, int lane, T* rec) {
   if constexpr (C::REM1) rec[C::RW - 1] = *reinterpret_cast<const T*>(tb + C::TAIL1_OFF + (long)lane * (long)sizeof(T));
 }
 
-template <class C, typename T>
+template <class C, typename T, bool OPAQUE = false>
 __device__ __forceinline__ void store_record(char* tb, int lane, const T* rec) {
   using V = typename Vec16<T>::type;
 #pragma unroll
   for (int c = 0; c < C::NC; ++c) {
     V v;
-    if constexpr (sizeof(T) == 8) { v.x = rec[c * 2]; v.y = rec[c * 2 + 1]; }
+    if constexpr (OPAQUE) {   // words gathered into their store tuple four at a time, never all 4-tuples at once
+      if constexpr (sizeof(T) == 8) { v.x = opaque_copy(rec[c * 2]); v.y = opaque_copy(rec[c * 2 + 1]); }
+      else { v.x = opaque_copy(rec[c * 4]); v.y = opaque_copy(rec[c * 4 + 1]); v.z = opaque_copy(rec[c * 4 + 2]); v.w = opaque_copy(rec[c * 4 + 3]); }
+    } else if constexpr (sizeof(T) == 8) { v.x = rec[c * 2]; v.y = rec[c * 2 + 1]; }
     else { v.x = rec[c * 4]; v.y = rec[c * 4 + 1]; v.z = rec[c * 4 + 2]; v.w = rec[c * 4 + 3]; }
     *reinterpret_cast<V*>(tb + (long)c * C::LPT * 16 + (long)lane * 16) = v;
+    if constexpr (OPAQUE) {
+      if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
   }
   if constexpr (C::REM2) {
     float2 v; v.x = rec[C::NC * C::VW]; v.y = rec[C::NC * C::VW + 1];
@@ -121,7 +134,7 @@ template <typename T> __device__ __forceinline__ T sel3(int c, T a, T b, T d) { 
 // Minimum wavefronts per SIMD the register allocation must leave room for.  1 = no constraint, except angular_rates fp64 on
 // the upper triangle with 6 lanes per target: unconstrained it takes 262 registers (one wavefront per SIMD, 1034 us per
 // 10^6-target tick); held to 256 it parks four doubles in scratch (32-44 B per lane) and runs two wavefronts: 647 us.
-// (The same constraint on the thread-per-target symmetric EKF in fp32 bought nothing: 188 vs 190 us, 252 B of scratch.)
+// (The thread-per-target symmetric EKF got under the limit by other means: opaque_copy above and kf_model_av_sym.hip.)
 template <class M, typename T, int G, int LAYOUT>
 constexpr int step_min_waves() { return (M::TYPE == ANGULAR_RATES && LAYOUT == LAYOUT_PACKED && G == 6 && sizeof(T) == 8) ? 2 : 1; }
 
@@ -183,6 +196,10 @@ kf_step_kernel(const StepArgs<T> a) {
   } else {
 #pragma unroll
     for (int w = 0; w < C::RW; ++w) mem[w] = 0;
+  }
+  if constexpr (EKF_SYM) {   // updated in place: the words must not stay tied to their load tuples (opaque_copy)
+#pragma unroll
+    for (int w = 0; w < C::RW; ++w) mem[w] = opaque_copy(mem[w]);
   }
   T* sQw = s_qr + C::QR_WORDS * wave;
   if constexpr (!PERQR) {
@@ -654,7 +671,7 @@ kf_step_kernel(const StepArgs<T> a) {
 #pragma unroll
       for (int w = 0; w < C::RW; ++w) mem[w] = rec[w];
     }
-    store_record<C, T>(tb, lt, mem);
+    store_record<C, T, EKF_SYM>(tb, lt, mem);
     if (i == 0) {
       if constexpr (INDEXED) {
         const long slot = slot_of;
