@@ -10,8 +10,11 @@
 // target_batch_c.h, so the filters run on the GPU.  Header-only, needs only <Eigen/Dense> and the
 // two C headers (no HIP headers).
 //
-// NOT compiled in the authoring environment (Eigen3 is absent there, SURVEY.md headline 3); it is
-// guarded so that it is inert where Eigen is missing.  Differences from the reference types:
+// Eigen3 is absent from the authoring environment (SURVEY.md headline 3), so this header has never met the real
+// library.  What it has met: a test-only stand-in for the Eigen members it uses (tests/host/eigen_standin, Eigen's
+// storage-order semantics) under g++ -Wall -Wextra -Werror, and tests/host/eigen_facade_test.cpp on the GPU -- every
+// call below against the same call on the C symbols, bitwise, with non-symmetric column-major Q / P0
+// (tests/test_eigen_facade.py).  It is guarded so that it is inert where Eigen is missing.  Differences from the reference types:
 // getTarget(id) returns a small value handle (the filter state lives in HBM, not in a host object);
 // MatrixXd arguments are converted to the row-major arrays the C ABI takes.
 #pragma once
