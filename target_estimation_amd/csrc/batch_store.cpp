@@ -2,6 +2,7 @@
 #include "batch_store.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -94,6 +95,7 @@ Batch::~Batch() {
   (void)hipFree(d_dtper_);
   if (h_pin_) (void)hipHostFree(h_pin_);
   if (h_cache_) (void)hipHostFree(h_cache_);
+  if (h_done_) (void)hipHostFree(h_done_);
 }
 
 long Batch::zigzag_min_bytes() {
@@ -503,6 +505,12 @@ void Batch::cache_reserve(long n) {
   cache_valid_ = false;
 }
 
+// TE_SPIN_WAIT=0 keeps the stream synchronisation (e.g. to leave the core to other threads)
+static bool spin_wait_enabled() {
+  static const bool on = [] { const char* e = std::getenv("TE_SPIN_WAIT"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 void Batch::flush() {
   const long k = (long)pending_.size();
   if (!k) return;
@@ -531,16 +539,53 @@ void Batch::flush() {
   p.meas = any_has ? d_pin_ + off_meas : nullptr; p.meas_ld = k;
   p.has_meas = (any_has && !all_has) ? reinterpret_cast<const unsigned char*>(d_pin_ + off_has) : nullptr;
   p.dt_per = reinterpret_cast<const double*>(d_pin_ + off_dt); p.dt = 0.0;
+  // With a current getter table the flush reports its own completion through a flag in host-mapped memory and the host
+  // spins on it instead of synchronising the stream (tools/launch_latency.hip: the runtime's completion path costs 4 us more
+  // than a PCIe write).  Up to one wavefront of queued targets the step kernel itself writes the table rows and the flag --
+  // ONE launch per flush; up to one workgroup of the outputs kernel that kernel does.
+  int seq = 0;
+  if (cache_valid_ && spin_wait_enabled() && k <= std::max<long>(ops_->L.tpw, kOutputsBlock)) {
+    if (!h_done_) {
+      TE_HIP_CHECK(hipHostMalloc((void**)&h_done_, 64, hipHostMallocMapped));
+      TE_HIP_CHECK(hipHostGetDevicePointer((void**)&d_done_, h_done_, 0));
+      *h_done_ = 0;
+    }
+    seq = ++done_seq_;
+    if (seq == 0) seq = ++done_seq_;
+  }
+  const bool fused = seq != 0 && k <= ops_->L.tpw;
+  if (fused) {
+    p.o_pose = d_cache_; p.o_twist = d_cache_ + 7 * n_; p.o_acc = d_cache_ + 13 * n_;
+    p.done_flag = d_done_; p.done_seq = seq;
+  }
   ops_->step(p, stream_);
-  if (cache_valid_) {   // keep the getter table current: only the stepped slots change
+  if (cache_valid_ && !fused) {   // keep the getter table current: only the stepped slots change
     OutArgs a;
     a.rec = d_rec_; a.idx = p.idx; a.n = k; a.by_slot = 1;
     a.pose = d_cache_; a.twist = d_cache_ + 7 * n_; a.acc = d_cache_ + 13 * n_;
     a.at_time = 0; a.t1 = 0.0; a.t_acc = t_acc_; a.t_base = d_tbase_;
+    if (seq != 0 && k <= kOutputsBlock) { a.done_flag = d_done_; a.done_seq = seq; }
+    else seq = 0;
     ops_->outputs(a, stream_);
   }
   TE_HIP_CHECK(hipGetLastError());
-  TE_HIP_CHECK(hipStreamSynchronize(stream_));   // the pinned block is rewritten by the next flush
+  // the pinned block is rewritten by the next flush, and the getters read the table right after this call
+  if (seq != 0) wait_done(seq);
+  else TE_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Batch::wait_done(int seq) {
+  // The signalling kernel is the last launch of the flush (in-order stream): once its flag is here, the step kernel has
+  // consumed the pinned inputs and the table rows are in host memory.  A round trip takes 10-20 us; after 2 ms of spinning
+  // something else is going on (a busy device, a debugger) and the runtime's own wait takes over.
+  const volatile int* flag = h_done_;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; ++spins) {
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return;
+    __builtin_ia32_pause();
+    if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+  }
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
 void Batch::outputs(const int* slots, long n, double* pose, double* twist, double* acc, bool at_time, double t1) {

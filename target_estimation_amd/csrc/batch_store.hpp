@@ -219,7 +219,9 @@ class Batch {
   std::vector<unsigned char> pending_mark_;
   double* d_dtper_ = nullptr;
   // Both live in pinned, device-mapped host memory: the kernels read the queued inputs and write the
-  // outputs there directly, so a flush is two launches and one stream synchronisation, no copies.
+  // outputs there directly, so a flush is two launches and no copies; when the getter table is current and the
+  // queue fits one workgroup the host does not even synchronise the stream but spins on a completion flag the
+  // outputs kernel stores behind its rows (wait_done; tools/launch_latency.hip: 9.4 us instead of 13.3 us of floor).
   void pin_reserve(long k);
   char* h_pin_ = nullptr;                    // idx int[cap] | dt double[cap] | meas T[7][cap] | has uchar[cap]
   char* d_pin_ = nullptr;                    // the same memory as the device sees it
@@ -230,6 +232,10 @@ class Batch {
   double* d_cache_ = nullptr;
   long cache_cap_ = 0;
   bool cache_valid_ = false;
+  int* h_done_ = nullptr;                    // completion flag of the last flush (host-mapped), and its device alias
+  int* d_done_ = nullptr;
+  int done_seq_ = 0;
+  void wait_done(int seq);                   // spin on *h_done_ == seq, falling back to hipStreamSynchronize
   void touch() { flush(); cache_valid_ = false; }   // call before anything that changes state
 };
 

@@ -21,7 +21,7 @@ constexpr int kIdMaxBatches = 8;         // per-batch counters of one resolve ca
 __device__ __forceinline__ unsigned id_hash(unsigned id, int log2cap) { return (id * 2654435761u) >> (32 - log2cap); }
 
 // insert (ids[s], batch << 26 | s) for s < n; ids are unique across the manager
-static __global__ void id_table_insert_kernel(unsigned* keys, unsigned* vals, int log2cap, const unsigned* ids, long n, unsigned batch) {
+__attribute__((unused)) static __global__ void id_table_insert_kernel(unsigned* keys, unsigned* vals, int log2cap, const unsigned* ids, long n, unsigned batch) {
   const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
   const unsigned mask = (1u << log2cap) - 1u;
@@ -43,7 +43,7 @@ struct ResolveCounters {
 };
 
 // epoch: a number that is different for every resolve call (seen[] keeps the epoch of the last call that touched a cell)
-static __global__ void id_resolve_kernel(const unsigned* keys, const unsigned* vals, int* seen, int log2cap, const unsigned* ids, long n,
+__attribute__((unused)) static __global__ void id_resolve_kernel(const unsigned* keys, const unsigned* vals, int* seen, int log2cap, const unsigned* ids, long n,
                                   int epoch, int* loc, ResolveCounters* counters) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   int out = -1;
@@ -72,7 +72,7 @@ static __global__ void id_resolve_kernel(const unsigned* keys, const unsigned* v
   }
 }
 
-static __global__ void id_select_kernel(const int* loc, long n, int batch, int* idx, unsigned char* found /* or null */) {
+__attribute__((unused)) static __global__ void id_select_kernel(const int* loc, long n, int batch, int* idx, unsigned char* found /* or null */) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   const int v = loc[e];

@@ -197,7 +197,13 @@ struct OutArgs {
   double t_acc;     // batch clock; target time = t_base[slot] + t_acc
   const double* t_base;
   int by_slot = 0;  // 1: output row = slot (scatter into a per-slot table) instead of the entry index
+  // One-workgroup launches only (n <= kOutputsBlock): after every row has been written, store done_seq to *done_flag
+  // (host-mapped memory).  A host thread that spins on the flag sees the rows without a stream synchronisation: the
+  // one-target ABI's round trip is a launch and a PCIe write instead of a launch and the runtime's completion path.
+  int* done_flag = nullptr;
+  int done_seq = 0;
 };
+constexpr int kOutputsBlock = 128;
 
 // Derived outputs of one target, from x only.
 //  current : updateTargetState + getEstimatedPose()/Twist()/Acceleration()
@@ -280,20 +286,26 @@ __global__ void outputs_kernel(const OutArgs a) {
   using C = Cfg<M, T, G, LAYOUT>;
   constexpr int N = C::N;
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= a.n) return;
-  const long slot = a.idx ? (long)a.idx[e] : e;
-  if (slot < 0) return;   // an entry that is not in this batch (device-resolved ids, id_resolve.hpp)
-  T x[N];
+  long slot = -1;
+  if (e < a.n) slot = a.idx ? (long)a.idx[e] : e;   // negative: an entry that is not in this batch (device-resolved ids, id_resolve.hpp)
+  if (slot >= 0) {
+    T x[N];
 #pragma unroll
-  for (int r = 0; r < N; ++r) x[r] = state_get<C, T>(a.rec, slot, r, N);
-  T d = 0;
-  if (a.at_time) d = (a.t1 != a.t1) ? (T)0 : (T)(a.t1 - (a.t_base[slot] + a.t_acc));
-  T pose7[7], twist6[6], acc6[6];
-  derive_outputs<M, T>(x, a.at_time != 0, d, pose7, twist6, acc6);
-  const long row = a.by_slot ? slot : e;
-  if (a.pose) for (int c = 0; c < 7; ++c) a.pose[row * 7 + c] = (double)pose7[c];
-  if (a.twist) for (int c = 0; c < 6; ++c) a.twist[row * 6 + c] = (double)twist6[c];
-  if (a.acc) for (int c = 0; c < 6; ++c) a.acc[row * 6 + c] = (double)acc6[c];
+    for (int r = 0; r < N; ++r) x[r] = state_get<C, T>(a.rec, slot, r, N);
+    T d = 0;
+    if (a.at_time) d = (a.t1 != a.t1) ? (T)0 : (T)(a.t1 - (a.t_base[slot] + a.t_acc));
+    T pose7[7], twist6[6], acc6[6];
+    derive_outputs<M, T>(x, a.at_time != 0, d, pose7, twist6, acc6);
+    const long row = a.by_slot ? slot : e;
+    if (a.pose) for (int c = 0; c < 7; ++c) a.pose[row * 7 + c] = (double)pose7[c];
+    if (a.twist) for (int c = 0; c < 6; ++c) a.twist[row * 6 + c] = (double)twist6[c];
+    if (a.acc) for (int c = 0; c < 6; ++c) a.acc[row * 6 + c] = (double)acc6[c];
+  }
+  if (a.done_flag != nullptr) {   // uniform; the launch is one workgroup (OutArgs::done_flag)
+    __threadfence_system();       // this thread's rows are visible to the host ...
+    __syncthreads();              // ... for every thread of the workgroup ...
+    if (threadIdx.x == 0) __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before the flag is
+  }
 }
 
 struct IntersectArgs {

@@ -25,6 +25,9 @@ struct OpsImpl {
     a.q_origin[0] = p.q_origin[0]; a.q_origin[1] = p.q_origin[1]; a.q_origin[2] = p.q_origin[2];
     a.q_radius = p.q_radius; a.q_delta = p.q_delta; a.q_pose = p.q_pose;
     a.reverse = p.reverse;
+    a.o_pose = p.o_pose; a.o_twist = p.o_twist; a.o_acc = p.o_acc; a.done_flag = p.done_flag; a.done_seq = p.done_seq;
+    if (p.o_pose && (!p.idx || p.n > C::TPW || !p.o_twist || !p.o_acc || !p.done_flag))
+      throw std::runtime_error("target_estimation_amd: the fused getter table needs an indexed launch of at most one wavefront of entries");
     static const int nt_env = [] { const char* e = std::getenv("TE_NT_MEAS"); return e ? std::atoi(e) : -1; }();
     a.nt_meas = nt_env >= 0 ? nt_env : p.nt_meas;
     if (p.q_delta && (p.idx || p.n_ticks > 1))
@@ -115,7 +118,7 @@ struct OpsImpl {
   }
   static void outputs(const OutArgs& a, hipStream_t s) {
     if (a.n <= 0) return;
-    hipLaunchKernelGGL((outputs_kernel<M, T, G, LAYOUT>), dim3((unsigned)((a.n + 127) / 128)), dim3(128), 0, s, a);
+    hipLaunchKernelGGL((outputs_kernel<M, T, G, LAYOUT>), dim3((unsigned)((a.n + kOutputsBlock - 1) / kOutputsBlock)), dim3(kOutputsBlock), 0, s, a);
   }
   static void pack_meas(const double* aos, long n, void* soa, long ld, hipStream_t s) {
     if (n <= 0) return;

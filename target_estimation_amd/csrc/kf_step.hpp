@@ -63,6 +63,15 @@ struct StepArgs {
   // measurements are read once per tick: nt_meas != 0 loads them with the nontemporal policy so that they do not push
   // state out of the Infinity Cache (set for batches large enough to zig-zag; TE_NT_MEAS overrides)
   int nt_meas;
+  // Indexed launches of at most ONE wavefront of entries (the queue of the one-target ABI, Batch::flush): o_pose != null
+  // makes the kernel also write the derived outputs of the stepped slots into the per-slot host table
+  // (pose [.][7], twist [.][6], acceleration [.][6]; what outputs_kernel would write) and then store done_seq to
+  // *done_flag (host-mapped): step, getter table and completion signal in one launch.
+  double* o_pose;
+  double* o_twist;
+  double* o_acc;
+  int* done_flag;
+  int done_seq;
 };
 
 template <typename T> __device__ __forceinline__ T load_meas(const T* p, int nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
@@ -126,6 +135,25 @@ __device__ __forceinline__ void store_record(char* tb, int lane, const T* rec) {
 }
 
 template <typename T> __device__ __forceinline__ T sel3(int c, T a, T b, T d) { return c == 0 ? a : (c == 1 ? b : d); }
+
+// StepArgs::o_pose: the row of the per-slot getter table for one stepped target (outputs_kernel's arithmetic on the same
+// posterior state), then the completion flag.  The launch has one wavefront of entries: once this wave's rows are visible to
+// the host (system-scope fence) lane 0 publishes the sequence number the host spins on.
+template <class M, typename T>
+__device__ __forceinline__ void write_outputs_row(const T* x, long slot, double* o_pose, double* o_twist, double* o_acc) {
+  T pose7[7], twist6[6], acc6[6];
+  derive_outputs<M, T>(x, false, (T)0, pose7, twist6, acc6);
+#pragma unroll
+  for (int c = 0; c < 7; ++c) o_pose[slot * 7 + c] = (double)pose7[c];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) o_twist[slot * 6 + c] = (double)twist6[c];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) o_acc[slot * 6 + c] = (double)acc6[c];
+}
+__device__ __forceinline__ void signal_done(int* flag, int seq, int lane) {
+  __threadfence_system();
+  if (lane == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // QUERY: the own-time sphere query of the target runs after the store, on the posterior state (kf_aux.hpp,
 // sphere_query); with G > 1 the state is first collected from the G lanes through the wave's LDS scratch.
@@ -682,25 +710,34 @@ kf_step_kernel(const StepArgs<T> a) {
       }
     }
   }
-  if constexpr (QUERY) {
-    T xq[N];
-    if constexpr (EKF_SYM) {
+  if constexpr (QUERY || INDEXED) {
+    bool want = QUERY;
+    if constexpr (INDEXED) want = a.o_pose != nullptr;   // uniform
+    if (want) {
+      T xq[N];
+      if constexpr (EKF_SYM) {
 #pragma unroll
-      for (int r = 0; r < N; ++r) xq[r] = mem[C::X_OFF + r];
-    } else if constexpr (G == 1) {
+        for (int r = 0; r < N; ++r) xq[r] = mem[C::X_OFF + r];
+      } else if constexpr (G == 1) {
 #pragma unroll
-      for (int r = 0; r < N; ++r) xq[r] = X_(r);
-    } else {
-      // local row q of lane i is row (q / KPL) K + (q % KPL) G + i of the state
-      wave_lds_fence();
+        for (int r = 0; r < N; ++r) xq[r] = X_(r);
+      } else {
+        // local row q of lane i is row (q / KPL) K + (q % KPL) G + i of the state
+        wave_lds_fence();
 #pragma unroll
-      for (int q = 0; q < RPL; ++q) EXA_((q / KPL) * K + (q % KPL) * G + i) = X_(q);
-      wave_lds_fence();
+        for (int q = 0; q < RPL; ++q) EXA_((q / KPL) * K + (q % KPL) * G + i) = X_(q);
+        wave_lds_fence();
 #pragma unroll
-      for (int r = 0; r < N; ++r) xq[r] = EXA_(r);
+        for (int r = 0; r < N; ++r) xq[r] = EXA_(r);
+      }
+      if constexpr (QUERY) {
+        if (valid && i == 0)
+          sphere_query<M, T>(xq, true, 0.0, 0.0, a.q_origin, a.q_radius, &a.q_delta[entry], a.q_pose ? &a.q_pose[entry * 7] : nullptr);
+      } else {
+        if (valid && i == 0) write_outputs_row<M, T>(xq, slot_of, a.o_pose, a.o_twist, a.o_acc);
+        signal_done(a.done_flag, a.done_seq, lane);
+      }
     }
-    if (valid && i == 0)
-      sphere_query<M, T>(xq, true, 0.0, 0.0, a.q_origin, a.q_radius, &a.q_delta[entry], a.q_pose ? &a.q_pose[entry * 7] : nullptr);
   }
 #undef P_
 #undef X_

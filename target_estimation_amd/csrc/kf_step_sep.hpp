@@ -429,6 +429,17 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
       if (a.has_meas != nullptr) a.nm_base[entry] += n_has;
     }
   }
+  if constexpr (INDEXED) {
+    if (a.o_pose != nullptr) {   // uniform: the getter table and the completion flag in the same launch (StepArgs::o_pose)
+      if (valid) {
+        T xq[N];
+#pragma unroll
+        for (int r = 0; r < N; ++r) xq[r] = XW_(r);
+        write_outputs_row<M, T>(xq, slot_of, a.o_pose, a.o_twist, a.o_acc);
+      }
+      signal_done(a.done_flag, a.done_seq, lane);
+    }
+  }
 #undef XW_
 #undef UWW_
 }

@@ -315,16 +315,22 @@ def _one(orc, i, dt, meas_row):
         orc._f("orc_target_add_measurement")(orc._at(i), float(dt), row.ctypes.data_as(C.POINTER(C.c_double)))
 
 
-@pytest.mark.parametrize("name,dtype", [("uniform_acceleration", "f64"), ("angular_rates", "f32"), ("angular_velocities", "f64")])
-def test_getter_table_stays_current(models, name, dtype):
+@pytest.mark.parametrize("name,dtype,lanes", [("uniform_acceleration", "f64", 0), ("angular_rates", "f32", 0), ("angular_velocities", "f64", 0),
+                                              ("uniform_velocity", "f64", 3), ("angular_rates", "f64", 106), ("angular_rates", "f32", 6),
+                                              ("angular_velocities", "f32", 101), ("angular_velocities", "f64", 6)])
+def test_getter_table_stays_current(models, name, dtype, lanes):
     """The one-target getters are served from a host table that a flush updates only for the stepped slots:
     after any mix of one-target steps, batch steps, erase (slots move) and re-creation every scalar getter
-    must equal the batch getter, which always runs the outputs kernel on the device."""
+    must equal the batch getter, which always runs the outputs kernel on the device.
+    A flush of up to one wavefront of queued targets writes the table rows from the step kernel itself (one launch, the
+    host spins on a completion flag); a longer queue goes through the outputs kernel: the 3-step and the 15-step
+    operations below hit both on the lanes-per-target layouts (10 or 21 targets per wavefront) and the first on the
+    thread-per-target ones."""
     rng = np.random.default_rng(21)
     N, dt = 37, 0.004
     p0, meas = synth_stream(name, N, 40, seed=23)
     ids = list(range(100, 100 + N))
-    mgr = te.TargetManager(model_path(name), dtype=dtype)
+    mgr = te.TargetManager(model_path(name), dtype=dtype, lanes_per_target=lanes)
     mgr.init_batch(np.array(ids, dtype=np.uint32), dt, 0.0, p0)
 
     def check():
@@ -341,7 +347,7 @@ def test_getter_table_stays_current(models, name, dtype):
     for s in range(30):
         op = s % 6
         if op in (0, 1, 2):                               # a few one-target steps, read back at once / later
-            for j in rng.choice(len(ids), size=3, replace=False):
+            for j in rng.choice(len(ids), size=15 if op == 2 else 3, replace=False):
                 mgr.update(ids[j], dt, meas[s][j % N] if rng.random() < 0.8 else None)
                 if op == 0:
                     mgr.getTargetPose(ids[j])             # flush per target (the reference test's loop)
