@@ -214,6 +214,7 @@ constexpr int kOutputsBlock = 128;
 //             angular_velocities.cpp:171-184, target_interface.cpp:123-140)
 template <class M, typename T>
 __device__ __forceinline__ void derive_outputs(const T* x, bool at_time, T d, T* pose7, T* twist6, T* acc6) {
+#pragma clang fp contract(off)   // the same roundings wherever this is inlined (see te_device_math.hpp)
   T R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   T pint[6] = {x[0], x[1], x[2], 0, 0, 0};  // pose_internal_
 #pragma unroll
@@ -328,6 +329,7 @@ struct IntersectArgs {
 template <class M, typename T>
 __device__ __forceinline__ void sphere_query(const T* x, bool own, double t1, double t, const double* origin, double radius,
                                              double* delta_out, double* pose_out /* [7] or null */) {
+#pragma clang fp contract(off)   // fused query, intersect kernel: the same roundings (te_device_math.hpp)
   T pose7[7], twist6[6], acc6[6];
   derive_outputs<M, T>(x, true, own ? (T)0 : (T)(t1 - t), pose7, twist6, acc6);
   const double px = (double)pose7[0] - origin[0], py = (double)pose7[1] - origin[1], pz = (double)pose7[2] - origin[2];

@@ -30,6 +30,13 @@ template <> struct Mth<float> {
   static __device__ __forceinline__ float abs(float x) { return ::fabsf(x); }
 };
 
+// The geometry helpers below (and derive_outputs, kf_aux.hpp) are inlined into several kernels -- the step kernels, the
+// outputs kernel, the fused getter-table epilogue of the indexed step.  Left to the compiler's default (contract = fast) the
+// SAME source rounds differently from one inlining context to the next (an a*b+c fused here, not there: one ulp in a
+// quaternion component), so they are compiled without contraction: one rounding sequence everywhere, and the one the
+// oracle's strict build and the reference's x86-64 build (no FMA target) use.  The filter products keep their explicit fma.
+#pragma clang fp contract(off)
+
 template <typename T> __device__ __forceinline__ constexpr T pi_v() { return (T)3.14159265358979323846; }
 
 // fmod(t, 2pi) for the reference's angle helpers.  IEEE fmod is exact, so wherever the quotient is
@@ -158,5 +165,7 @@ template <typename T> __device__ __forceinline__ void qtran_apply(T dt, const T*
     out[0] = q[0]; out[1] = q[1]; out[2] = q[2]; out[3] = q[3];
   }
 }
+
+#pragma clang fp contract(fast)   // back to hipcc's default for what follows
 
 }  // namespace te

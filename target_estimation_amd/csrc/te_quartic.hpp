@@ -53,6 +53,8 @@ __device__ __forceinline__ float cbrt_f(float x) { return ::cbrtf(x); }
 namespace te {
 #ifdef TE_QUARTIC_HOST
 using namespace qdetail;
+#else
+#pragma clang fp contract(off)   // one rounding sequence wherever the solver is inlined (te_device_math.hpp); the explicit fma calls stay
 #endif
 
 // value and derivative of the quartic c[0] + c[1] x + ... + c[4] x^4 (Horner)
@@ -209,5 +211,9 @@ TE_QDEV double first_crossing_quartic(const double* cin) {
   }
   return quartic_root_monotone(c, L, H, convex);
 }
+
+#ifndef TE_QUARTIC_HOST
+#pragma clang fp contract(fast)
+#endif
 
 }  // namespace te
