@@ -161,7 +161,7 @@ __device__ __forceinline__ void signal_done(int* flag, int seq, int lane) {
 // target_manager.hpp:85-87) from a table in HBM (L2-resident for 10^3 classes) instead of the one pair staged in LDS.
 // Minimum wavefronts per SIMD the register allocation must leave room for.  1 = no constraint, except angular_rates fp64 on
 // the upper triangle with 6 lanes per target: unconstrained it takes 262 registers (one wavefront per SIMD, 1034 us per
-// 10^6-target tick); held to 256 it parks four doubles in scratch (32-44 B per lane) and runs two wavefronts: 647 us.
+// 10^6-target tick); held to 256 it parks four doubles in scratch (32-56 B per lane) and runs two wavefronts: 647 us.
 // (The thread-per-target symmetric EKF got under the limit by other means: opaque_copy above and kf_model_av_sym.hip.)
 template <class M, typename T, int G, int LAYOUT>
 constexpr int step_min_waves() { return (M::TYPE == ANGULAR_RATES && LAYOUT == LAYOUT_PACKED && G == 6 && sizeof(T) == 8) ? 2 : 1; }
