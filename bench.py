@@ -128,7 +128,7 @@ HEADLINE = "cfg4_1gpu"
 
 DEFAULT_EXTRA = ("cfg2,cfg2_stream,cfg3,cfg3_stream,cfg4,cfg4_64,cfg5,cfg4_1gpu32,cfg5_1gpu,cfg5_1gpu64,"
                  "uv1m,uv1m32,ua1m64,ua1m,av1m64,av1m,ar1m64,ar1m,"
-                 "uv10m,ua10m,av4m64,ar4m64,av8m,ar8m,cfg4_4m,"
+                 "uv10m,ua10m,av4m64,ar4m64,av8m,ar8m,cfg4_4m,cfg4_1gpu_replay,cfg4_4m_replay,"
                  "ar1m_a90,av1m_a90,ar1m64_1kcls,ar1m64_1kcls_rand,ar100k64_1kcls,uv1m_1kcls,uv1m_full,uv1m_packed,ar1m_full,ar1m_packed,av1m_packed,ar1m64_full,av1m64_full,ar1m64_packed,av1m64_packed")
 DEFAULT_EXTRA_MULTI = "uv1m,ua1m64,av1m64,ar1m64,cfg4_64,cfg5,uv1m_strong,ar1m64_strong"
 
@@ -840,7 +840,17 @@ def main():
         if name == args.workload:
             continue
         try:
-            if name in MIXED:
+            if name.endswith("_replay"):
+                # The same population with the batches' chains FREE-RUNNING inside recorded graph blocks (one branch per batch,
+                # joined only at the end of a block): legal for a replay, where the measurements of later ticks are already
+                # there, not for a live stream, whose ticks arrive in lockstep.  Each chain runs ahead for a few ticks on its
+                # own batch -- 180 / 228 MB at 10^6 targets, which fits the Infinity Cache although the population does not
+                # (rocprofv3 kernel trace: AV x5 alone, then AR x5 alone).  Never `value`.
+                base = name[:-len("_replay")]
+                r = run_mixed(te, torch, base, args.extra_steps, 8, dist, rank, world, launch_mode="graph", reps=3)
+                r["name"] = name
+                r["launch_mode"] = "graph: one branch per batch, free-running inside blocks of ticks (replay only)"
+            elif name in MIXED:
                 small = sum(n for _, n in MIXED[name][1]) <= SMALL
                 r = run_mixed(te, torch, name, 512 if small else args.extra_steps, 64 if small else 8, dist, rank, world,
                               launch_mode="auto" if args.launch_mode == "fused" else args.launch_mode, reps=3)
@@ -859,7 +869,7 @@ def main():
             extras.append({"name": name, "error": str(exc)[:200]})
             torch.cuda.empty_cache()
             continue
-        attach_traffic(r["kernels"], name, traffic)
+        attach_traffic(r["kernels"], name[:-len("_replay")] if name.endswith("_replay") else name, traffic)
         tr = [k.get("traffic") for k in r["kernels"]]
         extras.append({k: r[k] for k in ("name", "dtype", "targets_per_gpu", "layout", "kernel", "cycles_per_s", "ms_per_step",
                                         "device_ms_per_step", "achieved_gbs", "algorithmic_bytes_per_cycle", "residency", "launch_mode")}
