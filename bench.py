@@ -888,9 +888,9 @@ def main():
         out["extra"] = extras
         # the HBM-bound rows (state > 1 GB) also go into `roofline`, where a reader of the top-level keys finds them
         out["roofline"]["hbm_bound"] = {e["name"]: {"achieved": e["achieved_gbs"], "frac": e["roofline_frac"], "cycles_per_s": e["cycles_per_s"]}
-                                        for e in extras if "error" not in e and e.get("residency", "").startswith("HBM-bound")}
+                                        for e in extras if "error" not in e and e.get("residency", "").startswith("HBM-bound") and not e["name"].endswith("_replay")}
         out["roofline"]["l3_assisted"] = {e["name"]: {"achieved": e["achieved_gbs"], "frac": e["roofline_frac"], "cycles_per_s": e["cycles_per_s"]}
-                                          for e in extras if "error" not in e and e.get("residency", "").startswith("L3-assisted")}
+                                          for e in extras if "error" not in e and e.get("residency", "").startswith("L3-assisted") and not e["name"].endswith("_replay")}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
