@@ -488,7 +488,7 @@ void Batch::pin_reserve(long k) {
   if (h_pin_) (void)hipHostFree(h_pin_);
   h_pin_ = nullptr; d_pin_ = nullptr; pin_cap_ = 0;
   const size_t bytes = (size_t)want * (sizeof(int) + sizeof(double) + 7 * elem_size() + 1) + 64;
-  TE_HIP_CHECK(hipHostMalloc((void**)&h_pin_, bytes, hipHostMallocMapped));
+  TE_HIP_CHECK(hipHostMalloc((void**)&h_pin_, bytes, hipHostMallocMapped | hipHostMallocCoherent));
   TE_HIP_CHECK(hipHostGetDevicePointer((void**)&d_pin_, h_pin_, 0));
   pin_cap_ = want;
 }
@@ -499,7 +499,7 @@ void Batch::cache_reserve(long n) {
   TE_HIP_CHECK(hipStreamSynchronize(stream_));
   if (h_cache_) (void)hipHostFree(h_cache_);
   h_cache_ = nullptr; d_cache_ = nullptr; cache_cap_ = 0;
-  TE_HIP_CHECK(hipHostMalloc((void**)&h_cache_, sizeof(double) * 19 * (size_t)want, hipHostMallocMapped));
+  TE_HIP_CHECK(hipHostMalloc((void**)&h_cache_, sizeof(double) * 19 * (size_t)want, hipHostMallocMapped | hipHostMallocCoherent));
   TE_HIP_CHECK(hipHostGetDevicePointer((void**)&d_cache_, h_cache_, 0));
   cache_cap_ = want;
   cache_valid_ = false;
@@ -546,12 +546,12 @@ void Batch::flush() {
   int seq = 0;
   if (cache_valid_ && spin_wait_enabled() && k <= std::max<long>(ops_->L.tpw, kOutputsBlock)) {
     if (!h_done_) {
-      TE_HIP_CHECK(hipHostMalloc((void**)&h_done_, 64, hipHostMallocMapped));
+      TE_HIP_CHECK(hipHostMalloc((void**)&h_done_, 64, hipHostMallocMapped | hipHostMallocCoherent));
       TE_HIP_CHECK(hipHostGetDevicePointer((void**)&d_done_, h_done_, 0));
       *h_done_ = 0;
     }
-    seq = ++done_seq_;
-    if (seq == 0) seq = ++done_seq_;
+    seq = (int)(++done_seq_ & 0x7fffffffu);   // never 0 (= "no flag"), wraps without overflow
+    if (seq == 0) seq = (int)(++done_seq_ & 0x7fffffffu);
   }
   const bool fused = seq != 0 && k <= ops_->L.tpw;
   if (fused) {

@@ -234,7 +234,7 @@ class Batch {
   bool cache_valid_ = false;
   int* h_done_ = nullptr;                    // completion flag of the last flush (host-mapped), and its device alias
   int* d_done_ = nullptr;
-  int done_seq_ = 0;
+  unsigned done_seq_ = 0;
   void wait_done(int seq);                   // spin on *h_done_ == seq, falling back to hipStreamSynchronize
   void touch() { flush(); cache_valid_ = false; }   // call before anything that changes state
 };
