@@ -1,4 +1,4 @@
-import sys, ctypes, os
+import sys, ctypes
 sys.path.insert(0, '.')
 import torch
 print("torch", torch.__version__)

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 import oracle
 import target_estimation_amd as te
-from conftest import synth_stream, MODEL_FILES
+from conftest import synth_stream
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 N = 64

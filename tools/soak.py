@@ -1,9 +1,8 @@
 #!/usr/bin/env python3
 """Soak run of tests/test_gpu_edge_cases.py::test_randomised_schedule_against_oracle over many seeds (GPU box).
 usage: python tools/soak.py <number of seeds>   (6 random schedules per seed)"""
-import sys, os
+import sys
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
-import numpy as np
 import conftest, oracle
 import test_gpu_edge_cases as t
 models = {k: oracle.load_model_yaml(conftest.model_path(k)) for k in conftest.MODEL_FILES}

@@ -3,7 +3,7 @@
 random masks, unnormalised quaternions of either sign, body rates up to 40 rad/s (unwrapped angles reach hundreds
 of radians).  The EKF model is kept away from pitch = +-pi/2, where the reference's Euler-angle Jacobians are
 singular (1/cos^2 pitch) and any two implementations diverge.  usage: python tools/torture.py"""
-import sys, os
+import sys
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np, torch
 import oracle, conftest
