@@ -45,33 +45,6 @@ def run(mode, steps):
             s1.wait_event(e2); s2.wait_event(e1)
 
 
-def graphed(mode, block=20):
-    """the same schedule recorded into a graph of `block` ticks (the capturing stream forks into s1 / s2 and joins at the end)"""
-    s0 = torch.cuda.Stream()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=s0):
-        e0 = torch.cuda.Event(); e0.record(s0)
-        s1.wait_event(e0); s2.wait_event(e0)
-        run(mode, block)
-        f1, f2 = torch.cuda.Event(), torch.cuda.Event()
-        f1.record(s1); f2.record(s2)
-        s0.wait_event(f1); s0.wait_event(f2)
-    return g
-
-
-if len(sys.argv) > 4 and sys.argv[4] == "graph":
-    for mode in ("A", "B", "C", "A", "B", "C"):
-        g = graphed(mode)
-        for _ in range(2): g.replay()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(20): g.replay()
-        torch.cuda.synchronize()
-        t = (time.perf_counter() - t0) / 400
-        byts = sum(b.algorithmic_bytes for b in batches) * N
-        print("graph mode %s: %.1f us per tick, %.0f GB/s" % (mode, t * 1e6, byts / t / 1e9), flush=True)
-    sys.exit(0)
-
 for mode in ("A", "B", "C", "A", "B", "C"):
     run(mode, 40)
     torch.cuda.synchronize()
