@@ -80,8 +80,13 @@ __device__ __forceinline__ void sep_linear_axis(T* x, T (&P)[NB][NB], const T (&
 // point fused on-GPU": one launch per tick instead of step + query.
 // PERQR: Q and R come from the target's own parameter class (a table in HBM, per-lane loads) instead of the one
 // shared pair read through the scalar cache.
+// Register budget the allocator must respect (wavefronts per SIMD it has to leave room for; 1 = unconstrained).  The
+// per-class angular_rates kernel in fp64 sits two registers over the three-wave limit (170 of 168) when left alone.
+template <class M, typename T, bool PERQR>
+constexpr int sep_min_waves() { return (PERQR && M::TYPE == ANGULAR_RATES && sizeof(T) == 8) ? 3 : 1; }
+
 template <class M, typename T, int LAYOUT, bool INDEXED, bool FUSED = false, bool QUERY = false, bool PERQR = false>
-__global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
+__global__ void __launch_bounds__(256, (sep_min_waves<M, T, PERQR>())) kf_step_sep_kernel(const StepArgs<T> a) {
   static_assert(!(QUERY && (INDEXED || FUSED)), "the fused query is for dense single-tick launches");
   static_assert(!(PERQR && (FUSED || QUERY)), "per-class Q/R: single-tick launches without the fused query");
   using C = Cfg<M, T, 1, LAYOUT>;
@@ -123,10 +128,25 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
   }
   const T dt = (T)dtd;
   const T* Qm = a.qr;
+  // PERQR: when every target of the wavefront belongs to ONE class -- the usual case, classes arrive in runs -- the row is
+  // read through the scalar cache like the single (Q, R) of a one-class batch (Qu, a uniform address); only a wavefront
+  // that mixes classes pays for per-lane gathers of its rows.
+  const T* Qu = a.qr;
+  bool cls_uniform = false;
+  int cls_own = 0;
   if constexpr (PERQR) {
-    if (valid) Qm = a.qr + (long)a.cls[slot_of] * C::QR_WORDS;
-    if constexpr ((C::QR_WORDS * sizeof(T)) % 16 == 0) Qm = static_cast<const T*>(__builtin_assume_aligned(Qm, 16));   // rows are whole 16-byte chunks: wide loads
+    if (valid) cls_own = a.cls[slot_of];
+    const int cls_first = __builtin_amdgcn_readfirstlane(cls_own);
+    cls_uniform = __all(!valid || cls_own == cls_first) != 0;   // (a ragged wave whose lane 0 is idle may take the per-lane path: same results)
+    Qu = a.qr + (long)cls_first * C::QR_WORDS;
   }
+  // the per-lane row, formed where it is needed (one register for the class instead of two for the address)
+  auto lane_row = [&]() -> const T* {
+    const T* q = a.qr + (long)cls_own * C::QR_WORDS;
+    if constexpr ((C::QR_WORDS * sizeof(T)) % 16 == 0) q = static_cast<const T*>(__builtin_assume_aligned(q, 16));   // rows are whole 16-byte chunks: wide loads
+    return q;
+  };
+  if constexpr (!PERQR) (void)lane_row;
   // the [p v (a)] chains.  Linear models: K of them, rows {i, i+K, i+2K}.  EKF: x, y, z with rows
   // {i, i+6} (position, velocity), plus the 6-state attitude group (rows 3..5, 9..11).
   constexpr int NLIN = M::EKF ? 3 : K;
@@ -223,14 +243,37 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
 #pragma unroll
   for (int i = 0; i < NLIN; ++i) {
     T xs[LB], Pb[LB][LB], Qb[LB][LB];
+    T r_meas;
 #pragma unroll
     for (int b = 0; b < LB; ++b) {
       xs[b] = XW_(i + STRIDE * b);
 #pragma unroll
-      for (int c = 0; c < LB; ++c) {
-        Pb[b][c] = mem[C::PWORD.v[i + STRIDE * b][i + STRIDE * c]];
-        if constexpr (HOIST_QR) Qb[b][c] = Qlin[i][b][c];
-        else Qb[b][c] = Qm[C::QWORD.v[i + STRIDE * b][i + STRIDE * c]];
+      for (int c = 0; c < LB; ++c) Pb[b][c] = mem[C::PWORD.v[i + STRIDE * b][i + STRIDE * c]];
+    }
+    if constexpr (HOIST_QR) {
+#pragma unroll
+      for (int b = 0; b < LB; ++b)
+#pragma unroll
+        for (int c = 0; c < LB; ++c) Qb[b][c] = Qlin[i][b][c];
+      r_meas = Rlin[i];
+    } else {
+      const T* Qsrc = PERQR ? lane_row() : Qm;
+      if constexpr (PERQR) {
+        if (cls_uniform) {   // wave-uniform branch: scalar loads from the one row
+#pragma unroll
+          for (int b = 0; b < LB; ++b)
+#pragma unroll
+            for (int c = 0; c < LB; ++c) Qb[b][c] = Qu[C::QWORD.v[i + STRIDE * b][i + STRIDE * c]];
+          r_meas = Qu[C::RWORD.v[i][i]];
+          Qsrc = nullptr;
+        }
+      }
+      if (Qsrc != nullptr) {
+#pragma unroll
+        for (int b = 0; b < LB; ++b)
+#pragma unroll
+          for (int c = 0; c < LB; ++c) Qb[b][c] = Qsrc[C::QWORD.v[i + STRIDE * b][i + STRIDE * c]];
+        r_meas = Qsrc[C::RWORD.v[i][i]];
       }
     }
     T y = 0;
@@ -242,9 +285,6 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
         UWW_(i - 3) = y;
       }
     }
-    T r_meas;
-    if constexpr (HOIST_QR) r_meas = Rlin[i];
-    else r_meas = Qm[C::RWORD.v[i][i]];
     sep_linear_axis<LB, T>(xs, Pb, Qb, r_meas, dt, has, y);
 #pragma unroll
     for (int b = 0; b < LB; ++b) {
@@ -332,13 +372,22 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
         v = F::fma(Pr[r][5], Jw[cc][2], v);
         nw[cc] = v;
       }
+      T qrow[6];
+      if constexpr (HOIST_QR) {
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        T qrc;
-        if constexpr (HOIST_QR) qrc = Qatt[r][c];
-        else qrc = Qm[C::QWORD.v[GR[r]][GR[c]]];
-        Pr[r][c] = (c < 3 ? nw[c < 3 ? c : 0] : Pr[r][c]) + qrc;
+        for (int c = 0; c < 6; ++c) qrow[c] = Qatt[r][c];
+      } else {
+        const T* Qsrc = PERQR ? lane_row() : Qm;
+        if (PERQR && cls_uniform) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) qrow[c] = Qu[C::QWORD.v[GR[r]][GR[c]]];
+        } else {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) qrow[c] = Qsrc[C::QWORD.v[GR[r]][GR[c]]];
+        }
       }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) Pr[r][c] = (c < 3 ? nw[c < 3 ? c : 0] : Pr[r][c]) + qrow[c];
     }
     if (has) {
       T S[3][3];
@@ -348,7 +397,8 @@ __global__ void __launch_bounds__(256) kf_step_sep_kernel(const StepArgs<T> a) {
         for (int c = 0; c < 3; ++c) {
           T rrc;
           if constexpr (HOIST_QR) rrc = Ratt[r][c];
-          else rrc = Qm[C::RWORD.v[3 + r][3 + c]];
+          else if (PERQR && cls_uniform) rrc = Qu[C::RWORD.v[3 + r][3 + c]];
+          else rrc = (PERQR ? lane_row() : Qm)[C::RWORD.v[3 + r][3 + c]];
           S[r][c] = Pr[r][c] + rrc;
         }
 #pragma unroll
