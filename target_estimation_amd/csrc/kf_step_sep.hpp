@@ -81,12 +81,13 @@ __device__ __forceinline__ void sep_linear_axis(T* x, T (&P)[NB][NB], const T (&
 // PERQR: Q and R come from the target's own parameter class (a table in HBM, per-lane loads) instead of the one
 // shared pair read through the scalar cache.
 // Register budget the allocator must respect (wavefronts per SIMD it has to leave room for; 1 = unconstrained).  The
-// per-class angular_rates kernel in fp64 sits two registers over the three-wave limit (170 of 168) when left alone.
-template <class M, typename T, bool PERQR>
-constexpr int sep_min_waves() { return (PERQR && M::TYPE == ANGULAR_RATES && sizeof(T) == 8) ? 3 : 1; }
+// per-class angular_rates kernel in fp64 on packed group blocks sits two registers over the three-wave limit (170 of 168) when
+// left alone; held to it, it parks 12-24 B per lane in scratch (grouped classes 162 -> 156 us per 10^6-target tick).
+template <class M, typename T, int LAYOUT, bool PERQR>
+constexpr int sep_min_waves() { return (PERQR && M::TYPE == ANGULAR_RATES && sizeof(T) == 8 && LAYOUT == LAYOUT_SEPARABLE_PACKED) ? 3 : 1; }
 
 template <class M, typename T, int LAYOUT, bool INDEXED, bool FUSED = false, bool QUERY = false, bool PERQR = false>
-__global__ void __launch_bounds__(256, (sep_min_waves<M, T, PERQR>())) kf_step_sep_kernel(const StepArgs<T> a) {
+__global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR>())) kf_step_sep_kernel(const StepArgs<T> a) {
   static_assert(!(QUERY && (INDEXED || FUSED)), "the fused query is for dense single-tick launches");
   static_assert(!(PERQR && (FUSED || QUERY)), "per-class Q/R: single-tick launches without the fused query");
   using C = Cfg<M, T, 1, LAYOUT>;
