@@ -41,15 +41,21 @@ def _check_classes(mgr, orcs, ids, members, dtype, what):
     return worst
 
 
+@pytest.mark.parametrize("order", ["random", "runs"])
 @pytest.mark.parametrize("name,dtype", [("angular_rates", "f64"), ("uniform_velocity", "f64"), ("angular_velocities", "f32"),
                                          ("uniform_acceleration", "f32")])
-def test_hundred_thousand_targets_thousand_classes_one_batch(models, name, dtype):
-    """10^5 targets, 10^3 distinct (Q, R, P0): one batch (= one launch per tick), parity vs the oracle on 40 classes."""
+def test_hundred_thousand_targets_thousand_classes_one_batch(models, name, dtype, order):
+    """10^5 targets, 10^3 distinct (Q, R, P0): one batch (= one launch per tick), parity vs the oracle on 40 classes.
+    order = "random": every target draws its class, so every wavefront mixes classes (per-lane gathers of the class rows);
+    "runs": targets of a class are neighbours (runs of about 100), so most wavefronts take the wave-uniform path that reads the
+    row through the scalar cache, and the wavefronts that straddle two runs the other one."""
     m = models[name]
     N, NC, dt, ticks = 100_000, 1000, 0.004, 5
     rng = np.random.default_rng(5)
     Q, R, P0 = _scaled_classes(m, NC, rng)
     class_of = rng.integers(0, NC, N).astype(np.uint32)
+    if order == "runs":
+        class_of = np.sort(class_of)
     from target_estimation_amd.streams import make_stream
     st = make_stream(te.MODEL_TYPES[name], N, ticks, dt, 99)
     p0 = st["p0"].cpu().numpy()
