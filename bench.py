@@ -271,7 +271,8 @@ def run_workload(te, torch, name, steps, warmup, lanes=0, targets=None, dist=Non
         ticks = max(gb, min(ring_want, steps + warmup) // gb * gb)
     else:
         ticks = max(2, min(stream_ticks, steps + warmup, RING_BYTES // (7 * es * n_targets)))
-    st = make_stream(mtype, n_targets, ticks, dt, seed + 1000 * rank, **VARIANTS.get(name, {}))
+    # ranks of a sharded run take consecutive target ranges of ONE keyed stream (csrc/stream_gen.hpp), in the batch precision
+    st = make_stream(mtype, n_targets, ticks, dt, seed, dtype=dtype, first_target=rank * n_targets, **VARIANTS.get(name, {}))
     has = st["has_meas"]    # [ticks, N] uint8 or None
     ids = np.arange(n_targets, dtype=np.uint32) + rank * n_targets  # global ids: rank-contiguous shards
     if name in CLASSES:   # every target draws one of NC scaled copies of the model file's (Q, R, P0)
@@ -286,7 +287,8 @@ def run_workload(te, torch, name, steps, warmup, lanes=0, targets=None, dist=Non
     else:
         mgr.init_batch(ids, dt, 0.0, st["p0"].cpu().numpy())
     b = mgr.batches()[0]
-    meas = st["meas"].to(b.torch_dtype()).contiguous()   # [ticks, 7, N] in the batch precision
+    meas = st["meas"]   # [ticks, 7, N], generated in the batch precision
+    assert meas.dtype == b.torch_dtype()
     del st
     torch.cuda.synchronize()
     passes = 1
@@ -369,7 +371,7 @@ def run_mixed(te, torch, name, steps, warmup, dist=None, rank=0, world=1, stream
     streams, base = [], 0
     for k, (model, n) in enumerate(parts):
         mt = te.MODEL_TYPES[model]
-        st = make_stream(mt, n, ticks, dt, seed + 1000 * rank + 17 * k)
+        st = make_stream(mt, n, ticks, dt, seed + 17 * k, dtype=dtype, first_target=rank * n)
         ids = np.arange(n, dtype=np.uint32) + base + rank * 16_000_000
         base += n
         params = _model_params(model)
@@ -378,8 +380,8 @@ def run_mixed(te, torch, name, steps, warmup, dist=None, rank=0, world=1, stream
         del st
     batches = mgr.batches()
     assert len(batches) == len(parts)
-    meas = [m.to(b.torch_dtype()).contiguous() for m, b in zip(streams, batches)]
-    del streams
+    meas = streams
+    assert all(m.dtype == b.torch_dtype() for m, b in zip(meas, batches))
     origin = np.zeros(3)
     outs = [(torch.empty(b.size, dtype=torch.float64, device="cuda"), torch.empty((b.size, 7), dtype=torch.float64, device="cuda"))
             for b in batches] if intersect else None
@@ -561,25 +563,26 @@ def parity_report(te, torch, parts, dtype, seed, n_sample=256, checkpoints=(1, 1
     import oracle
     from target_estimation_amd.streams import make_stream
     rep = dict(targets_per_model=n_sample, ticks=list(checkpoints), oracle="oracle/te_oracle.c, same precision (%s); parity UNPINNED: "
-               "the reference cannot be built here (no Eigen3), the oracle is a restatement" % dtype,
+               "the reference cannot be built here (no Eigen3), the oracle is a restatement; both sides generate the keyed stream "
+               "themselves (target_stream_fill_dev on the GPU, oracle/te_stream.c on the CPU)" % dtype,
                tolerance=("x: 1e-10 + 1e-10|x|, P: 1e-9 max|P|" if dtype == "f64" else "x: 2e-3 + 1e-4|x|, P: 2e-3 max|P|"), models={})
     dt, ticks = 1.0 / 250.0, max(checkpoints)
     for k, (model, _) in enumerate(parts):
         m = oracle.load_model_yaml(os.path.join(ROOT, "models", "model_%s_params.yaml" % model))
-        st = make_stream(te.MODEL_TYPES[model], n_sample, ticks, dt, seed + 17 * k)
-        p0 = st["p0"].cpu().numpy()
+        st = make_stream(te.MODEL_TYPES[model], n_sample, ticks, dt, seed + 17 * k, dtype=dtype)
+        ref = oracle.stream_fill(te.MODEL_TYPES[model], seed + 17 * k, n_sample, ticks, dt, dtype=dtype)   # the CPU regenerates the stream
+        p0 = ref["p0"]
         ids = np.arange(n_sample, dtype=np.uint32)
         mgr = te.TargetManager(os.path.join(ROOT, "models", "model_%s_params.yaml" % model), dtype=dtype)
         mgr.set_stream(torch.cuda.current_stream().cuda_stream)
         mgr.init_batch(ids, dt, 0.0, p0)
         b = mgr.batches()[0]
-        meas = st["meas"].to(b.torch_dtype()).contiguous()
-        meas_host = meas.to(torch.float64).cpu().numpy()           # the oracle sees what the kernel saw
+        meas = st["meas"]
         orc = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], p0, dt, dtype=dtype)
         r = dict(layout=b.layout, ids_exact=bool((b.slot_ids() == ids).all()), max_abs_x=[], max_rel_P=[])
         for s in range(ticks):
             b.step(dt, meas[s])
-            orc.step(dt, np.ascontiguousarray(meas_host[s].T))
+            orc.step(dt, ref["meas"][s])
             if s + 1 in checkpoints:
                 x, P = mgr.get_state_batch(ids)
                 xo, Po = orc.state()
@@ -590,14 +593,76 @@ def parity_report(te, torch, parts, dtype, seed, n_sample=256, checkpoints=(1, 1
     return rep
 
 
-def gather_report(te, torch, dist, rank, world, workload="ar1m64", ticks=16):
+class GatherTimeout(TimeoutError):
+    pass
+
+
+def configs0_report(te, torch, steps=(1000, 10000)):
+    """BASELINE.json configs[0]: 1 target, uniform-velocity model file, the reference integration test's loop (init, then per
+    step update(id, dt, meas) + getTargetPose + getTargetTwist; test/target_manager_test.cpp:125-146) on the reference
+    test's own stream.  CPU: the oracle port, one thread, the loop in C (oracle.harness_run).  GPU: the same loop through
+    the library's ten reference symbols (one target: a latency path, reported for completeness, never `value`)."""
+    import ctypes as C
+    import numpy as np
+    import oracle
+    m = oracle.load_model_yaml(os.path.join(ROOT, "models", "model_uniform_velocity_params.yaml"))
+    dt = 1.0 / m["frequency"]
+    stream = oracle.ref_test_stream(n_models=1)[0]           # [10000, 7]
+    out = dict(workload="1 target, model_uniform_velocity_params.yaml, the reference test's stream (libstdc++ default_random_engine, "
+               "N(0, 0.01), line to (0.2, 0.3, 0.4)); per step: update + getTargetPose + getTargetTwist", dt=dt, rows=[])
+    lib = te.capi.lib()
+    path = os.path.join(ROOT, "models", "model_uniform_velocity_params.yaml").encode()
+    for n in steps:
+        meas = np.ascontiguousarray(stream[:n])
+        best = 1e9
+        for _ in range(5):
+            t0 = time.perf_counter()
+            pose_c, twist_c = oracle.harness_run(m["model"], m["Q"], m["R"], m["P"], meas, dt)
+            best = min(best, time.perf_counter() - t0)
+        h = lib.target_manager_new(path)
+        p0 = np.ascontiguousarray(meas[0])
+        lib.target_manager_init(h, 0, dt, p0.ctypes.data_as(te.capi.c_double_p), 0.0)
+        pose = np.zeros((n, 7)); twist = np.zeros((n, 6))
+        mp, pp, tp = (a.ctypes.data_as(te.capi.c_double_p) for a in (meas, pose, twist))
+        dbl = C.sizeof(C.c_double)
+        t0 = time.perf_counter()
+        for i in range(n):
+            lib.target_manager_update_meas(h, 0, dt, C.cast(C.addressof(mp.contents) + 7 * dbl * i, te.capi.c_double_p))
+            lib.target_manager_get_est_pose(h, 0, C.cast(C.addressof(pp.contents) + 7 * dbl * i, te.capi.c_double_p))
+            lib.target_manager_get_est_twist(h, 0, C.cast(C.addressof(tp.contents) + 6 * dbl * i, te.capi.c_double_p))
+        gpu_s = time.perf_counter() - t0
+        lib.target_manager_delete(h)
+        out["rows"].append(dict(steps=n, cpu_oracle_1thread_s=best, cpu_cycles_per_s=n / best, cpu_us_per_step=best / n * 1e6,
+                                gpu_ten_symbol_abi_s=gpu_s, gpu_us_per_step=gpu_s / n * 1e6, gpu_cycles_per_s=n / gpu_s,
+                                end_position_gpu=pose[-1, :3].tolist(), end_position_cpu=pose_c[-1, :3].tolist(),
+                                max_abs_pose_difference=float(np.abs(pose - pose_c).max()),
+                                max_abs_twist_difference=float(np.abs(twist - twist_c).max())))
+    return out
+
+
+def gather_report(te, torch, dist, rank, world, workload="ar1m64", ticks=16, deadline_s=60.0):
     """The library's RCCL pose gather (target_manager_gather_pose_*: direct sends to rank 0 on a second stream behind an
     event).  Exposed = begin + wait with nothing else running; overlapped = begin, then `ticks` ticks, then wait: what
     the ticks cost on top of their own time is what the gather did NOT hide."""
     from target_estimation_amd.dist import PoseGather
     r = run_workload(te, torch, workload, ticks, 4, dist=dist, rank=rank, world=world, reps=2, keep=True)
     mgr, b, meas, ids, dt = r.pop("_mgr")
+    # Bounded: a peer that never arrives (communicator set-up is collective) must not hang the run.  A watchdog thread ends
+    # the process with a diagnostic after deadline_s; the waits themselves poll hipEventQuery against the same deadline
+    # (target_manager_gather_pose_wait_for).  Nothing is re-executed.
+    import threading
+    t_end = time.monotonic() + deadline_s
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(deadline_s + 5.0):
+            print("bench.py rank %d: pose gather still not finished %.0f s after its start (communicator set-up or a peer's "
+                  "send/recv never completed); giving up" % (rank, deadline_s + 5.0), file=sys.stderr)
+            sys.stderr.flush()
+            os._exit(3)
+    threading.Thread(target=watchdog, daemon=True).start()
     g = PoseGather(mgr)
+    g.deadline = t_end
     counts = g.counts()
     clock = Clock(torch, dist)
 
@@ -624,7 +689,8 @@ def gather_report(te, torch, dist, rank, world, workload="ar1m64", ticks=16):
     exposed = min(timed(only_gather) for _ in range(5))
     t_ticks = min(timed(only_ticks) for _ in range(5))
     t_both = min(timed(both) for _ in range(5))
-    out = dict(name="gather_pose", workload=workload, n_gpus=world, rows_per_rank=counts[0], rows_total=sum(counts),
+    done.set()
+    out = dict(name="gather_pose", workload=workload, n_gpus=world, comm_ranks=g.world, rows_per_rank=counts[0], rows_total=sum(counts),
                bytes_to_root=sum(counts) * 56, gather_pose_ms_exposed=exposed, ticks=ticks, ticks_ms=t_ticks,
                ticks_plus_gather_ms=t_both, gather_pose_ms_overlapped=max(0.0, t_both - t_ticks),
                transport="RCCL ncclSend/ncclRecv to rank 0 on a second stream" if world > 1 else "world size 1: the root's own rows only (no peer traffic)")
@@ -669,6 +735,106 @@ def attach_traffic(kernels, workload, traffic):
     for k in kernels:
         t = rows.get(k["kernel"])
         k["traffic"] = (t["hbm_read_bytes"] + t["hbm_write_bytes"]) if t else None
+
+
+def make_line(args, res, dom, world, traffic):
+    # THE LINE: what the contract asks for and nothing else (the driver parses the last stdout line out of a bounded tail;
+    # round 2's 30 KB line did not parse).  Everything else goes to the side file named in config.side_file and to stderr.
+    out = {
+        "metric": "KF predict+update cycles/sec over N targets",
+        "value": res["cycles_per_s"], "unit": "cycles/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": res["dtype"], "data": "synthetic",
+        "config": {"workload": res["desc"], "name": res["name"], "motion_model": res["model"],
+                   "targets_per_gpu": res["targets_per_gpu"], "targets_total": res["targets_per_gpu"] * world,
+                   "P_layout": res["layout"], "launch_mode": res["launch_mode"],
+                   "state_bytes_per_gpu": res["state_bytes"], "residency": res["residency"].split(":")[0].split(" (")[0],
+                   "side_file": os.path.relpath(side_path(args), ROOT)},
+        "roofline": {"bound": "hbm", "achieved": dom["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": dom["achieved_gbs"] / HBM_PEAK_GBS, "traffic": dom.get("traffic"),
+                     "kernel": dom["kernel"], "algorithmic_bytes_per_unit": dom["algorithmic_bytes_per_unit"],
+                     "units_per_launch": dom["units_per_launch"], "avg_launch_ms": dom["avg_launch_ms"],
+                     "tick_frac": res["achieved_gbs"] / HBM_PEAK_GBS,
+                     "traffic_source": traffic_source(traffic) if dom.get("traffic") else None},
+    }
+    return out
+
+
+LINE_LIMIT = 4096   # bytes of the one stdout line (the driver keeps a bounded tail of stdout and parses its last line)
+
+
+def side_path(args):
+    return os.path.abspath(args.side_file or os.environ.get("TE_BENCH_SIDE") or os.path.join(ROOT, "bench_extra.json"))
+
+
+def write_side(args, obj):
+    """Everything that is not the line (extras, per-kernel table, parity sample, configs[0], gather): one JSON file."""
+    path = side_path(args)
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path + ".tmp", "w") as f:
+            json.dump(obj, f, indent=1)
+        os.replace(path + ".tmp", path)
+    except OSError as exc:
+        print("bench.py: could not write %s: %s" % (path, exc), file=sys.stderr)
+
+
+def compact_line(out):
+    """The line as it will be printed: floats to 6 significant digits, and never longer than LINE_LIMIT -- optional keys are
+    dropped (last resort) rather than printing a line the driver cannot parse."""
+    def rnd(o):
+        if isinstance(o, float):
+            return float("%.6g" % o) if math.isfinite(o) else None
+        if isinstance(o, dict):
+            return {k: rnd(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [rnd(v) for v in o]
+        return o
+    line = rnd(out)
+    for drop in (None, "parity", ("config", "residency"), ("roofline", "traffic_source"), ("cpu_baseline", "sample")):
+        if drop is not None:
+            if isinstance(drop, tuple):
+                line.get(drop[0], {}).pop(drop[1], None)
+            else:
+                line.pop(drop, None)
+        if len(json.dumps(line)) + 1 <= LINE_LIMIT:
+            break
+    assert len(json.dumps(line)) + 1 <= LINE_LIMIT, "bench line too long"
+    return line
+
+
+def traffic_source(traffic):
+    meta = traffic.get("_meta", {})
+    return "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes) collected at commit %s" % meta.get("commit", "unknown")
+
+
+def parity_summary(rep):
+    """One short string for the line; the full sample is in the side file."""
+    if "models" not in rep:
+        return "partial (oracle unpinned)"
+    dx = max(max(r["max_abs_x"]) for r in rep["models"].values())
+    dP = max(max(r["max_rel_P"]) for r in rep["models"].values())
+    ids = all(r["ids_exact"] for r in rep["models"].values())
+    return "partial: oracle unpinned (reference unbuildable here); GPU vs oracle on %d targets/model after %s ticks: max|dx| %.2g, max|dP|/max|P| %.2g, ids %s" % (
+        rep["targets_per_model"], "/".join(str(t) for t in rep["ticks"]), dx, dP, "exact" if ids else "MISMATCH")
+
+
+_MAPS = os.environ.get("TE_BENCH_MAPS")   # diagnostic: keep /proc/self/maps current on disk (to resolve the PCs of a profiler-side abort)
+
+
+def maps_checkpoint(tag):
+    if not _MAPS:
+        return
+    try:
+        with open("/proc/self/maps") as f, open(_MAPS + ".tmp", "w") as g:
+            g.write("# after workload %s\n" % tag)
+            g.write(f.read())
+        os.replace(_MAPS + ".tmp", _MAPS)
+        with open(_MAPS + ".progress", "a") as g:
+            g.write("%s done\n" % tag)
+    except OSError:
+        pass
 
 
 # ------------------------------------------------------------------------------------------------ rank start-up
@@ -737,10 +903,10 @@ def main():
     ap.add_argument("--extra-steps", type=int, default=24)
     ap.add_argument("--stream-ticks", type=int, default=0, help="ticks of synthetic measurements kept in HBM and cycled through; 0 = default")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--gather", action="store_true",
-                    help="N > 1: every K ticks gather all ranks' pose7 rows to rank 0 through the library's RCCL gather on a second "
-                         "stream, overlapped with the next ticks; reports gather_pose_ms overlapped vs exposed")
-    ap.add_argument("--no-gather", action="store_true", help="skip the gather report (N = 1 runs it on a one-rank communicator)")
+    ap.add_argument("--gather", action="store_true", help="(kept for compatibility: the gather report is on by default)")
+    ap.add_argument("--no-gather", action="store_true", help="skip the gather report (it runs AFTER the line has been printed when N > 1)")
+    ap.add_argument("--gather-deadline", type=float, default=60.0, help="seconds the pose gather may take before the run gives up (exit 3)")
+    ap.add_argument("--side-file", default="", help="where everything that is not the line goes (default bench_extra.json next to bench.py)")
     ap.add_argument("--launch-mode", default="auto", choices=["auto", "python", "sequence", "graph", "fused"],
                     help="how the per-tick launches are enqueued (always one kernel launch per batch per tick, except 'fused')")
     ap.add_argument("--dry-run", action="store_true", help="no device work: rank start-up, rendezvous, barriers, timing protocol and "
@@ -787,56 +953,61 @@ def main():
     traffic = load_traffic()
     attach_traffic(res["kernels"], args.workload, traffic)
     dom = max(res["kernels"], key=lambda k: k["units_per_launch"] * k["algorithmic_bytes_per_unit"])
-    out = {
-        "metric": "KF predict+update cycles/sec over N targets",
-        "value": res["cycles_per_s"], "unit": "cycles/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": res["dtype"], "data": "synthetic",
-        "config": {"workload": res["desc"], "name": res["name"], "motion_model": res["model"],
-                   "targets_per_gpu": res["targets_per_gpu"], "targets_total": res["targets_per_gpu"] * world,
-                   "P_layout": res["layout"], "dt": 0.004, "launch_mode": res["launch_mode"],
+    out = make_line(args, res, dom, world, traffic)
+    side = {
+        "line_of": "bench.py " + " ".join(sys.argv[1:]),
+        "config": {"dt": 0.004,
                    "timing": "median of %d repetitions of %d steps (min %.4f, max %.4f ms/step; %.1f ms timed in all)" % (
                        res["reps"], args.steps, res["ms_per_step_min"], res["ms_per_step_max"], res["timed_total_s"] * 1e3),
-                   "measurements": "synthetic, resident in HBM as a ring of %d ticks (%d MB) that the run cycles through" % (
-                       res["measurement_ring_ticks"], res["measurement_ring_bytes"] // 1000000),
-                   "state_bytes_per_gpu": res["state_bytes"], "residency": res["residency"],
-                   "sharding": "contiguous id ranges per rank, no data-path collective"},
-        "roofline": {"bound": "hbm", "achieved": dom["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": dom["achieved_gbs"] / HBM_PEAK_GBS, "traffic": dom.get("traffic"),
-                     "kernel": dom["kernel"],
-                     "kernel_note": "dominant kernel of the tick (largest share of the bytes).  avg_launch_ms = the tick's device time over the "
+                   "measurements": "synthetic (counter-based generator of the library, csrc/stream_gen.hpp), resident in HBM as a ring of "
+                                   "%d ticks (%d MB) that the run cycles through" % (
+                                       res["measurement_ring_ticks"], res["measurement_ring_bytes"] // 1000000),
+                   "residency": res["residency"], "sharding": "contiguous id ranges per rank, no data-path collective"},
+        "roofline": {"kernel_note": "dominant kernel of the tick (largest share of the bytes).  avg_launch_ms = the tick's device time over the "
                                     "timed region (HIP events on the launch stream) x this kernel's share of it; the share comes from one HIP event "
                                     "between consecutive launches in a pass with the timed region's launch order, right after it",
-                     "algorithmic_bytes_per_unit": dom["algorithmic_bytes_per_unit"], "units_per_launch": dom["units_per_launch"],
-                     "avg_launch_ms": dom["avg_launch_ms"],
                      "bytes_rule": "bytes the kernel reads + writes per target: 2n + 2|P stored| + measurement words read (3 linear, 7 angular) "
                                    "(+6 unwrap words, angular); SURVEY 8d's full-P figure for this model is survey_full_P_bytes_per_unit",
                      "survey_full_P_bytes_per_unit": SURVEY_WORDS[dom["model"]] * (8 if res["dtype"] == "f64" else 4),
                      "tick": {"achieved": res["achieved_gbs"], "frac": res["achieved_gbs"] / HBM_PEAK_GBS,
                               "algorithmic_bytes_per_step": res["algorithmic_bytes_per_step"], "device_ms_per_step": res["device_ms_per_step"],
                               "note": "all kernels of the tick over the timed region itself (events on the launch stream)"},
-                     "kernels": res["kernels"],
-                     "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes)" if dom.get("traffic") else None},
+                     "kernels": res["kernels"]},
     }
     if world == 1 and rank == 0 and not args.no_cpu:
         try:
-            out["cpu_baseline"] = cpu_baseline(parts, res["dtype"])
+            cb = cpu_baseline(parts, res["dtype"])
+            out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample")}
+            side["cpu_baseline"] = cb
         except Exception as exc:
-            out["cpu_baseline"] = {"error": str(exc)[:300]}
+            out["cpu_baseline"] = {"error": str(exc)[:200]}
         try:
-            out["parity"] = parity_report(te, torch, parts, res["dtype"], seed)
+            side["parity"] = parity_report(te, torch, parts, res["dtype"], seed)
+            out["parity"] = parity_summary(side["parity"])
         except Exception as exc:   # a diagnostic: never let it break the bench line
-            out["parity"] = {"error": str(exc)[:300]}
+            side["parity"] = {"error": str(exc)[:300]}
+        try:
+            side["configs0"] = configs0_report(te, torch)
+        except Exception as exc:
+            side["configs0"] = {"error": str(exc)[:300]}
     if world == 1 and rank == 0:
         try:
             bw = copy_bandwidth(torch)
-            out["roofline"]["measured_copy_gbs"] = bw["copy"]
-            out["roofline"]["measured_triad_gbs"] = bw["triad"]
+            side["roofline"]["measured_copy_gbs"] = bw["copy"]
+            side["roofline"]["measured_triad_gbs"] = bw["triad"]
         except Exception as exc:
-            out["roofline"]["copy_bandwidth_error"] = str(exc)[:200]
-    # Extra workloads in the same line.  One GPU: the full list.  Several GPUs: one 10^6-targets-per-GPU workload per YAML
-    # motion model plus the configs' per-GPU shares, every rank in lockstep (same barriers, max over ranks).
+            side["roofline"]["copy_bandwidth_error"] = str(exc)[:200]
+    maps_checkpoint(args.workload)
+    # N > 1: the scaling line goes out FIRST (the driver's curve must not depend on anything below); the extras, and the
+    # one RCCL exchange the path offers, come after it and land in the side file.
+    if world > 1:
+        if dist is not None:
+            dist.barrier()
+        if rank == 0:
+            emit(compact_line(out))
+            write_side(args, dict(side, line=out))
+    # Extra workloads.  One GPU: the full list.  Several GPUs: one 10^6-targets-per-GPU workload per YAML motion model plus
+    # the configs' per-GPU shares, every rank in lockstep (same barriers, max over ranks).
     extra_names = [e for e in (args.extra if world == 1 else args.extra_multi).split(",") if e]
     extras = []
     for name in extra_names:
@@ -879,26 +1050,38 @@ def main():
                       | {"roofline_frac": r["achieved_gbs"] / HBM_PEAK_GBS, "n_gpus": world,
                          "traffic_per_step": (sum(tr) if all(t is not None for t in tr) else None)})
         torch.cuda.empty_cache()
-    if (args.gather or world == 1) and not args.no_gather:
+        maps_checkpoint(name)
+    # RCCL needs one GPU per rank: a gloo rehearsal (several ranks on ONE GPU) cannot create the communicator
+    if not args.no_gather and (world == 1 or dist.get_backend() == "nccl"):
         try:
-            gr = gather_report(te, torch, dist, rank, world)
+            gr = gather_report(te, torch, dist, rank, world, deadline_s=args.gather_deadline)
             extras.append(gr)
-            out["config"]["gather_pose_ms"] = {"exposed": gr["gather_pose_ms_exposed"], "overlapped": gr["gather_pose_ms_overlapped"],
-                                               "rows_total": gr["rows_total"], "ticks_overlapped_with": gr["ticks"]}
+            side["gather_pose_ms"] = {"exposed": gr["gather_pose_ms_exposed"], "overlapped": gr["gather_pose_ms_overlapped"],
+                                      "rows_total": gr["rows_total"], "ticks_overlapped_with": gr["ticks"], "comm_ranks": gr["comm_ranks"]}
+        except TimeoutError as exc:
+            # a peer never arrived: say so and leave non-zero -- never re-exec, never wait for ever (the line is out already)
+            print("bench.py: pose gather did not finish: %s" % exc, file=sys.stderr)
+            if rank == 0:
+                write_side(args, dict(side, line=out, extra=extras, gather_pose_error=str(exc)))
+            sys.stderr.flush()
+            os._exit(3)
         except Exception as exc:
             extras.append({"name": "gather_pose", "error": str(exc)[:300]})
     if extras:
-        out["extra"] = extras
-        # the HBM-bound rows (state > 1 GB) also go into `roofline`, where a reader of the top-level keys finds them
-        out["roofline"]["hbm_bound"] = {e["name"]: {"achieved": e["achieved_gbs"], "frac": e["roofline_frac"], "cycles_per_s": e["cycles_per_s"]}
-                                        for e in extras if "error" not in e and e.get("residency", "").startswith("HBM-bound") and not e["name"].endswith("_replay")}
-        out["roofline"]["l3_assisted"] = {e["name"]: {"achieved": e["achieved_gbs"], "frac": e["roofline_frac"], "cycles_per_s": e["cycles_per_s"]}
-                                          for e in extras if "error" not in e and e.get("residency", "").startswith("L3-assisted") and not e["name"].endswith("_replay")}
+        side["extra"] = extras
+        # the HBM-bound rows (state > 1 GB) apart, where a reader finds them
+        side["roofline"]["hbm_bound"] = {e["name"]: {"achieved": e["achieved_gbs"], "frac": e["roofline_frac"], "cycles_per_s": e["cycles_per_s"]}
+                                         for e in extras if "error" not in e and e.get("residency", "").startswith("HBM-bound") and not e["name"].endswith("_replay")}
+        side["roofline"]["l3_assisted"] = {e["name"]: {"achieved": e["achieved_gbs"], "frac": e["roofline_frac"], "cycles_per_s": e["cycles_per_s"]}
+                                           for e in extras if "error" not in e and e.get("residency", "").startswith("L3-assisted") and not e["name"].endswith("_replay")}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        emit(out)
+        write_side(args, dict(side, line=out))
+        print(json.dumps(dict(side, line=out)), file=sys.stderr)
+        if world == 1:
+            emit(compact_line(out))
 
 
 if __name__ == "__main__":

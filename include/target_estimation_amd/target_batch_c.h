@@ -234,6 +234,32 @@ int target_batch_gate_update_dev(target_batch_c* b, const double* delta_dev, con
 /* AoS doubles [n][7] (host layout of the reference) -> SoA [7][ld] in the batch precision, on device */
 int target_batch_pack_meas_dev(target_batch_c* b, const double* meas_aos_dev, long n, void* meas_soa_dev, long ld);
 
+/* ---- synthetic measurement streams (SURVEY 8d "Synthetic inputs") ------------------------------------------ */
+/* Counter-based generator: every number is a pure function of (seed, target, tick, component) -- splitmix64 keys, Box-Muller
+ * normals with fixed-sequence log / sin / cos -- so the GPU fills its measurement ring with one kernel and a CPU checker
+ * regenerates the same doubles bit for bit (csrc/stream_gen.hpp has the definition; it widens the generator of the
+ * reference's integration test, test/target_manager_test.cpp:82-115, to a population: per-target start, velocity,
+ * acceleration (uniform_acceleration), body rate; xyz + N(0, 0.01^2); quaternion = Qtran(dt, omega)^(tick+1) applied to the
+ * identity).  Target i of a call is target first_target + i of the stream (ranks of a sharded run pass their offset).
+ *   availability < 1 : a target has a measurement on a tick with that probability (has_meas_dev receives the bytes)
+ *   rpy_noise  > 0   : the measured orientation is the true one times a small random rotation (rad, per axis) */
+typedef struct target_stream_c {
+  int model;                 /* TARGET_* motion model */
+  unsigned long long seed;
+  long first_target;
+  double dt;                 /* tick length: tick s is time (s + 1) dt */
+  double availability;       /* 1 = every target measured on every tick */
+  double rpy_noise;          /* 0 = noiseless quaternion, as in the reference's test */
+} target_stream_c;
+/* ticks first_tick .. first_tick + n_ticks - 1 for n_targets targets: meas_dev = SoA ring [n_ticks][7][ld] (tick_stride
+ * elements between ticks) in precision dtype (TARGET_DTYPE_*; values are generated in double and rounded once);
+ * has_meas_dev [n_ticks][has_stride] bytes or NULL.  Asynchronous on hip_stream. */
+int target_stream_fill_dev(const target_stream_c* spec, long n_targets, long first_tick, long n_ticks, int dtype, void* meas_dev,
+                           long tick_stride, long ld, unsigned char* has_meas_dev, long has_stride, void* hip_stream);
+/* pose0_dev [n][7]: the pose to create target i with (start position + measurement noise, identity orientation);
+ * truth_dev [n][12]: p, v, a, omega of the generating motion.  Either may be NULL.  Device doubles. */
+int target_stream_truth_dev(const target_stream_c* spec, long n_targets, double* pose0_dev, double* truth_dev, void* hip_stream);
+
 /* ---- multi-GPU: gather of the estimated poses to one rank over xGMI (RCCL) ---------------------------- */
 /* One process per GPU, every rank owns a shard of the targets (no collective in the predict/update path).  What the
  * reference's node does with the filtered poses every tick is publish them (src/target_manager_ros.cpp:78-87); across
@@ -253,6 +279,9 @@ target_comm_c* target_comm_new(const char* id128, int rank, int world);
 void target_comm_delete(target_comm_c* comm);
 int target_manager_gather_pose_begin(target_manager_c* self, target_comm_c* comm, int root, const long* counts, double* recv_dev);
 int target_manager_gather_pose_wait(target_comm_c* comm, float* device_ms);
+/* the same with a deadline (the done event is polled with hipEventQuery): 0 finished, 1 still in flight after timeout_s
+ * seconds (a peer that never posted its send / recv; nothing is cancelled), < 0 error */
+int target_manager_gather_pose_wait_for(target_comm_c* comm, double timeout_s, float* device_ms);
 
 /* ---- measurement ingest: the ROS node's mailbox / has-measurement / expiry policy --------------- */
 /* Transport-agnostic restatement of class Measurement (target_manager_ros.hpp:74-134) and

@@ -5,5 +5,5 @@ package.  Nothing under target_estimation_amd/ does.  See te_oracle.h for the pa
 """
 from .oracle import (  # noqa: F401
     MODELS, MODEL_DIMS, OracleBatch, OracleGate, OracleTarget, build, load, load_model_yaml,
-    ref_test_stream, lowest_real_root, poly_roots,
+    ref_test_stream, lowest_real_root, poly_roots, harness_run, stream_fill, stream_sample,
 )

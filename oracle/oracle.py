@@ -83,6 +83,9 @@ def load(fast=False):
     lib.orc_poly_roots.argtypes = [dp, C.c_int, dp]
     lib.orc_max_threads.restype = C.c_int
     lib.orc_ref_test_stream.argtypes = [dp, C.c_int, C.c_int, C.c_double, dp, dp]
+    lib.orc_harness_run_f64.argtypes = [C.c_int, dp, dp, dp, dp, C.c_long, C.c_double, dp, dp]
+    lib.orc_stream_fill.argtypes = [C.c_int, C.c_ulonglong, C.c_long, C.c_long, C.c_long, C.c_long, C.c_double, C.c_double,
+                                    C.c_double, C.c_int, dp, C.POINTER(C.c_ubyte), dp, dp]
     _libs[key] = lib
     return lib
 
@@ -265,3 +268,43 @@ def poly_roots(coeffs):
     out = np.zeros(2 * (len(c) - 1))
     k = load().orc_poly_roots(_dp(c), len(c), _dp(out))
     return out[:2 * k:2] + 1j * out[1:2 * k:2]
+
+
+def harness_run(model, Q, R, P0, meas, dt):
+    """The reference test's loop for one target, entirely in C: returns (est_pose [n,7], est_twist [n,6])."""
+    meas = _d(meas)
+    n = meas.shape[0]
+    pose = np.empty((n, 7)); twist = np.empty((n, 6))
+    load().orc_harness_run_f64(int(model), _dp(_d(Q)), _dp(_d(R)), _dp(_d(P0)), _dp(meas), n, float(dt), _dp(pose), _dp(twist))
+    return pose, twist
+
+
+def stream_fill(model, seed, n_targets, n_ticks, dt, first_target=0, first_tick=0, availability=1.0, rpy_noise=0.0, dtype="f64"):
+    """CPU twin of the product's stream generator (oracle/te_stream.c): dict(p0 [N,7], meas [ticks,N,7] -- the
+    reference's row layout, values as a ring of precision `dtype` holds them --, has_meas [ticks,N] uint8 or None,
+    truth [N,12] = p v a omega).  Bit-identical to target_stream_fill_dev / target_stream_truth_dev."""
+    N, T = int(n_targets), int(n_ticks)
+    meas = np.empty((T, N, 7)); p0 = np.empty((N, 7)); truth = np.empty((N, 12))
+    has = np.empty((T, N), dtype=np.uint8) if availability < 1.0 else None
+    load().orc_stream_fill(int(model), int(seed), int(first_target), N, int(first_tick), T, float(dt), float(availability),
+                           float(rpy_noise), 1 if dtype == "f32" else 0, _dp(meas),
+                           None if has is None else has.ctypes.data_as(C.POINTER(C.c_ubyte)), _dp(p0), _dp(truth))
+    return dict(p0=p0, meas=meas, has_meas=has, truth=truth)
+
+
+def stream_sample(model, seed, targets, n_ticks, dt, first_tick=0, availability=1.0, rpy_noise=0.0, dtype="f64"):
+    """The rows of stream_fill for an arbitrary set of targets (e.g. a random sample of a 10^6-target population):
+    dict(p0 [k,7], meas [ticks,k,7], has_meas [ticks,k] or None, truth [k,12])."""
+    targets = np.asarray(targets, dtype=np.int64)
+    k, T = len(targets), int(n_ticks)
+    meas = np.empty((T, k, 7)); p0 = np.empty((k, 7)); truth = np.empty((k, 12))
+    has = np.empty((T, k), dtype=np.uint8) if availability < 1.0 else None
+    one = np.empty((max(T, 1), 7)); h1 = np.empty(max(T, 1), dtype=np.uint8)
+    lib = load()
+    for j, tg in enumerate(targets):
+        lib.orc_stream_fill(int(model), int(seed), int(tg), 1, int(first_tick), T, float(dt), float(availability), float(rpy_noise),
+                            1 if dtype == "f32" else 0, _dp(one), h1.ctypes.data_as(C.POINTER(C.c_ubyte)), _dp(p0[j]), _dp(truth[j]))
+        meas[:, j] = one[:T]
+        if has is not None:
+            has[:, j] = h1[:T]
+    return dict(p0=p0, meas=meas, has_meas=has, truth=truth)

@@ -189,3 +189,19 @@ int orc_gate_update(orc_gate* g, int exists, const double* pose7, double pos_th,
 #define RFMOD fmodf
 #define RFABS fabsf
 #include "te_oracle_impl.h"
+
+/* ------------------------------------------------------------------------- */
+/* The reference's integration-test loop for ONE target, in C (for timing configs[0] without a Python loop around it):
+ * _manager.init(type, id, dt, 0.0, Q, R, P, meas.row(0)) then n x { update(id, dt, meas_i); getTargetPose; getTargetTwist }
+ * (generateEstimation, test/target_manager_test.cpp:125-146). */
+/* ------------------------------------------------------------------------- */
+void orc_harness_run_f64(int model, const double* Q, const double* R, const double* P0, const double* meas, long n, double dt,
+                         double* est_pose, double* est_twist) {
+  orc_target_f64 tg;
+  orc_target_init_f64(&tg, model, 0u, dt, 0.0, Q, R, P0, meas, 0, 0);
+  for (long i = 0; i < n; ++i) {
+    orc_target_add_measurement_f64(&tg, dt, meas + 7 * i);
+    orc_target_get_pose_f64(&tg, est_pose + 7 * i);
+    orc_target_get_twist_f64(&tg, est_twist + 6 * i);
+  }
+}

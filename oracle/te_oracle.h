@@ -129,6 +129,18 @@ int orc_poly_roots(const double* coeffs, int ncoeffs, double* roots_re_im);
 
 int orc_max_threads(void);
 
+/* one target through the reference test's loop (test/target_manager_test.cpp:125-146), est_pose [n][7], est_twist [n][6] */
+void orc_harness_run_f64(int model, const double* Q, const double* R, const double* P0, const double* meas, long n, double dt,
+                         double* est_pose, double* est_twist);
+
+/* CPU twin of the product's counter-based stream generator (te_stream.c; definition: csrc/stream_gen.hpp) */
+void orc_stream_truth(int model, unsigned long long seed, long target, double* truth12, double* pose0);
+int orc_stream_measurement(int model, unsigned long long seed, long target, long tick, double dt, double availability,
+                           double rpy_noise, double* meas7);
+void orc_stream_fill(int model, unsigned long long seed, long first_target, long n_targets, long first_tick, long n_ticks,
+                     double dt, double availability, double rpy_noise, int f32, double* meas, unsigned char* has,
+                     double* pose0, double* truth);
+
 #ifdef __cplusplus
 }
 #endif

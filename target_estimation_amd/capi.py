@@ -21,6 +21,12 @@ class BatchSequence(C.Structure):
                 ("delta_dev", C.c_void_p), ("pose_dev", C.c_void_p), ("ring_ticks", C.c_long)]
 
 
+class StreamSpec(C.Structure):
+    """target_stream_c of target_batch_c.h"""
+    _fields_ = [("model", C.c_int), ("seed", C.c_ulonglong), ("first_target", C.c_long), ("dt", C.c_double),
+                ("availability", C.c_double), ("rpy_noise", C.c_double)]
+
+
 SIGNATURES = {
     # target_manager_c.h (the reference's ten symbols)
     "target_manager_new": (C.c_void_p, [C.c_char_p]),
@@ -77,6 +83,7 @@ SIGNATURES = {
     "target_comm_delete": (None, [C.c_void_p]),
     "target_manager_gather_pose_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_long), C.c_void_p]),
     "target_manager_gather_pose_wait": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "target_manager_gather_pose_wait_for": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(C.c_float)]),
     "target_ingest_new": (C.c_void_p, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p]),
     "target_ingest_delete": (None, [C.c_void_p]),
     "target_ingest_set_expiration_time": (None, [C.c_void_p, C.c_double]),
@@ -105,6 +112,9 @@ SIGNATURES = {
     "target_manager_step_sequence_all": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_long, C.c_int, c_double_p, C.c_double, C.c_int]),
     "target_batch_step_fused": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long]),
     "target_batch_get_est_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double]),
+    "target_stream_fill_dev": (C.c_int, [C.POINTER(StreamSpec), C.c_long, C.c_long, C.c_long, C.c_int, C.c_void_p, C.c_long, C.c_long,
+                                         C.c_void_p, C.c_long, C.c_void_p]),
+    "target_stream_truth_dev": (C.c_int, [C.POINTER(StreamSpec), C.c_long, C.c_void_p, C.c_void_p, C.c_void_p]),
     "target_batch_pack_meas_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_long]),
 }
 

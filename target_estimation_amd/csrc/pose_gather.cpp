@@ -3,9 +3,11 @@
 
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <stdexcept>
+#include <thread>
 
 #include "hip_check.hpp"
 #include "target_manager.hpp"
@@ -89,39 +91,52 @@ PoseComm::~PoseComm() {
 
 void PoseComm::begin(TargetManager* m, int root, const long* counts, double* recv_dev) {
   if (root < 0 || root >= world_) throw std::invalid_argument("target_estimation_amd: gather: bad root");
-  const long mine = m->posesToDevice(nullptr, 0, nullptr);   // rows this manager holds
-  if (counts[rank_] != mine) throw std::invalid_argument("target_estimation_amd: gather: counts[rank] differs from the manager's size");
+  const long mine = counts[rank_];
+  if (mine < 0) throw std::invalid_argument("target_estimation_amd: gather: negative row count");
   if (rank_ == root && !recv_dev && mine > 0) throw std::invalid_argument("target_estimation_amd: gather: the root needs a receive buffer");
-  hipStream_t compute = m->stream();
-  if (mine > send_cap_) {
+  if (mine > send_cap_ && rank_ != root) {
     if (in_flight_) TE_HIP_CHECK(hipEventSynchronize(done_));
     (void)hipFree(send_);
+    send_ = nullptr; send_cap_ = 0;
     TE_HIP_CHECK(hipMalloc((void**)&send_, sizeof(double) * 7 * mine));
     send_cap_ = mine;
   }
-  // the previous gather reads the send buffer: the outputs kernels of this one wait for it ON THE DEVICE
-  if (in_flight_) TE_HIP_CHECK(hipStreamWaitEvent(compute, done_, 0));
   long offset = 0;
   for (int r = 0; r < rank_; ++r) offset += counts[r];
-  // the root's own rows go straight into the receive buffer; every other rank fills its send buffer
-  double* own = (rank_ == root) ? recv_dev + offset * 7 : send_;
-  m->posesToDevice(own, mine, compute);
+  hipStream_t compute = nullptr;
+  // One critical section of the manager: row count checked against counts[rank], stream read, waits and outputs kernels
+  // enqueued -- a concurrent init / erase / setStream cannot fall between them (it either precedes the check, which then
+  // throws before anything is queued, or follows the launches).
+  m->posesForGather(mine, [&](long, hipStream_t st) -> double* {
+    compute = st;
+    // the previous gather reads the send buffer: the outputs kernels of this one wait for it ON THE DEVICE
+    if (in_flight_) TE_HIP_CHECK(hipStreamWaitEvent(compute, done_, 0));
+    // the root's own rows go straight into the receive buffer; every other rank fills its send buffer
+    return (rank_ == root) ? recv_dev + offset * 7 : send_;
+  });
   TE_HIP_CHECK(hipEventRecord(ready_, compute));
   TE_HIP_CHECK(hipStreamWaitEvent(stream_, ready_, 0));
   TE_HIP_CHECK(hipEventRecord(start_, stream_));
   if (world_ > 1) {
     check(rccl().GroupStart(), "ncclGroupStart");
+    int rc = 0;
+    const char* failed = nullptr;
     if (rank_ == root) {
       long off = 0;
-      for (int r = 0; r < world_; ++r) {
-        if (r != root && counts[r] > 0)
-          check(rccl().Recv(recv_dev + off * 7, (size_t)counts[r] * 7, kNcclDouble, r, comm_, stream_), "ncclRecv");
+      for (int r = 0; r < world_ && rc == 0; ++r) {
+        if (r != root && counts[r] > 0) {
+          rc = rccl().Recv(recv_dev + off * 7, (size_t)counts[r] * 7, kNcclDouble, r, comm_, stream_);
+          if (rc != 0) failed = "ncclRecv";
+        }
         off += counts[r];
       }
     } else if (mine > 0) {
-      check(rccl().Send(send_, (size_t)mine * 7, kNcclDouble, root, comm_, stream_), "ncclSend");
+      rc = rccl().Send(send_, (size_t)mine * 7, kNcclDouble, root, comm_, stream_);
+      if (rc != 0) failed = "ncclSend";
     }
-    check(rccl().GroupEnd(), "ncclGroupEnd");
+    const int rc_end = rccl().GroupEnd();   // always: a failed Send / Recv must not leave the group open for the next call
+    if (rc != 0) check(rc, failed);
+    check(rc_end, "ncclGroupEnd");
   }
   TE_HIP_CHECK(hipEventRecord(done_, stream_));
   in_flight_ = true;
@@ -132,6 +147,22 @@ void PoseComm::wait() {
   TE_HIP_CHECK(hipEventSynchronize(done_));
   in_flight_ = false;
   timed_ = true;
+}
+
+bool PoseComm::wait_for(double timeout_s) {
+  if (!in_flight_) return true;
+  const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s);
+  for (;;) {
+    const hipError_t e = hipEventQuery(done_);
+    if (e == hipSuccess) break;
+    if (e != hipErrorNotReady) TE_HIP_CHECK(e);
+    (void)hipGetLastError();   // hipErrorNotReady is not an error to keep
+    if (std::chrono::steady_clock::now() >= t_end) return false;   // still in flight: the caller decides
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+  in_flight_ = false;
+  timed_ = true;
+  return true;
 }
 
 float PoseComm::last_ms() {

@@ -38,6 +38,9 @@ class PoseComm {
   // first waits (on the device) for the previous one: there is one send buffer.
   void begin(TargetManager* m, int root, const long* counts, double* recv_dev);
   void wait();
+  // the same with a deadline: polls the done event (hipEventQuery) for at most timeout_s; false = still in flight
+  // (nothing is cancelled: a later wait() / wait_for() / the destructor picks it up)
+  bool wait_for(double timeout_s);
   // device time of the last gather, from its start event to its end event (after wait())
   float last_ms();
 

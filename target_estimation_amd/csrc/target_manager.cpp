@@ -905,6 +905,22 @@ long TargetManager::posesToDevice(double* out_dev, long capacity, hipStream_t st
   return rows;
 }
 
+long TargetManager::posesForGather(long expect_rows, const std::function<double*(long, hipStream_t)>& prepare) {
+  lock_guard<mutex> lg(target_lock_);   // count, stream and the outputs launches in ONE critical section
+  long rows = 0;
+  for (auto& b : batches_) rows += b->size();
+  if (rows != expect_rows) throw std::invalid_argument("target_estimation_amd: gather: counts[rank] differs from the manager's size");
+  double* out_dev = prepare(rows, stream_);
+  if (!out_dev && rows > 0) throw std::invalid_argument("target_estimation_amd: gather: no destination for the pose rows");
+  long off = 0;
+  for (auto& b : batches_) {
+    if (!b->size()) continue;
+    b->outputs_dev(out_dev + off * 7, nullptr, nullptr, false, 0.0);
+    off += b->size();
+  }
+  return rows;
+}
+
 void TargetManager::setStream(hipStream_t s) {
   lock_guard<mutex> lg(target_lock_);
   for (auto& b : batches_) { b->synchronize(); b->set_stream(s); }

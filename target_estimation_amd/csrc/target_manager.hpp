@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -132,6 +133,10 @@ class TargetManager {
   // pose7 rows (doubles) of every target, batch after batch in slot order, into out_dev [size()][7] on stream `st`
   // (the gather's send side, pose_gather.hpp); out_dev == null only counts.  Returns the number of rows.
   long posesToDevice(double* out_dev, long capacity, hipStream_t st);
+  // The gather's enqueue step, atomic with respect to init / erase / setStream: under the manager's lock, checks that the
+  // manager holds expect_rows rows, calls prepare(rows, stream) -- which may enqueue waits on that stream and returns the
+  // destination [rows][7] -- and launches the outputs kernels into it.  Returns the row count.
+  long posesForGather(long expect_rows, const std::function<double*(long, hipStream_t)>& prepare);
   void synchronize();
   int dtype() const { return dtype_; }
   bool defaultsLoaded() const { return default_values_loaded_; }

@@ -12,6 +12,7 @@
 #include "../../include/target_estimation_amd/target_batch_c.h"
 #include "measurement_ingest.hpp"
 #include "pose_gather.hpp"
+#include "stream_gen.hpp"
 #include "target_manager.hpp"
 
 using te::Batch;
@@ -458,6 +459,16 @@ int target_manager_gather_pose_wait(target_comm_c* comm, float* device_ms) {
   });
 }
 
+int target_manager_gather_pose_wait_for(target_comm_c* comm, double timeout_s, float* device_ms) {
+  int pending = 0;
+  const int rc = guarded("target_manager_gather_pose_wait_for", [&] {
+    if (!comm) throw std::invalid_argument("NULL communicator");
+    if (!((te::PoseComm*)comm)->wait_for(timeout_s)) { pending = 1; return; }
+    if (device_ms) *device_ms = ((te::PoseComm*)comm)->last_ms();
+  });
+  return rc != 0 ? rc : pending;
+}
+
 // ---------------------------------------------------------------- measurement ingest
 target_ingest_c* target_ingest_new(target_manager_c* manager, int type, const double* Q, const double* R, const double* P0) {
   te::MeasurementIngest* ing = nullptr;
@@ -499,6 +510,25 @@ long target_ingest_tick(target_ingest_c* ingest, double dt, double now, unsigned
     }
   });
   return n;
+}
+
+// ---------------------------------------------------------------- synthetic measurement streams
+int target_stream_fill_dev(const target_stream_c* sp, long n_targets, long first_tick, long n_ticks, int dtype, void* meas_dev,
+                           long tick_stride, long ld, unsigned char* has_meas_dev, long has_stride, void* hip_stream) {
+  return guarded("target_stream_fill_dev", [&] {
+    if (!sp) throw std::invalid_argument("NULL stream description");
+    if (dtype != TARGET_DTYPE_F64 && dtype != TARGET_DTYPE_F32) throw std::invalid_argument("unknown dtype");
+    te::stream_fill(te::StreamSpec{sp->model, (uint64_t)sp->seed, sp->first_target, sp->dt, sp->availability, sp->rpy_noise}, n_targets,
+                    first_tick, n_ticks, dtype == TARGET_DTYPE_F32, meas_dev, tick_stride, ld, has_meas_dev, has_stride, (hipStream_t)hip_stream);
+  });
+}
+
+int target_stream_truth_dev(const target_stream_c* sp, long n_targets, double* pose0_dev, double* truth_dev, void* hip_stream) {
+  return guarded("target_stream_truth_dev", [&] {
+    if (!sp) throw std::invalid_argument("NULL stream description");
+    te::stream_truth(te::StreamSpec{sp->model, (uint64_t)sp->seed, sp->first_target, sp->dt, sp->availability, sp->rpy_noise}, n_targets,
+                     pose0_dev, truth_dev, (hipStream_t)hip_stream);
+  });
 }
 
 }  // extern "C"

@@ -127,8 +127,17 @@ class PoseGather:
         import ctypes as C
         from . import capi
         ms = C.c_float()
-        if self._lib.target_manager_gather_pose_wait(self._h, C.byref(ms)) != 0:
-            raise RuntimeError("target_manager_gather_pose_wait failed: %s" % capi.last_error())
+        deadline = getattr(self, "deadline", None)   # time.monotonic() value: bounded wait (a peer may never arrive)
+        if deadline is None:
+            if self._lib.target_manager_gather_pose_wait(self._h, C.byref(ms)) != 0:
+                raise RuntimeError("target_manager_gather_pose_wait failed: %s" % capi.last_error())
+        else:
+            import time
+            rc = self._lib.target_manager_gather_pose_wait_for(self._h, max(0.0, deadline - time.monotonic()), C.byref(ms))
+            if rc < 0:
+                raise RuntimeError("target_manager_gather_pose_wait_for failed: %s" % capi.last_error())
+            if rc == 1:
+                raise TimeoutError("pose gather still in flight at its deadline (rank %d of %d)" % (self.rank, self.world))
         return (self._recv if self.rank == self.root else None), float(ms.value)
 
     def close(self):

@@ -56,12 +56,95 @@ def test_driver_style_launch_is_accepted():
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
 
 
+def _fake_result():
+    """A result record of the shape run_mixed() returns, with the longest strings bench.py can produce."""
+    sys.path.insert(0, ROOT)
+    import bench
+    desc = max((v[0] for v in list(bench.WORKLOADS.values()) + list(bench.MIXED.values())), key=len)
+    kern = "kf_step_sep_kernel<ModelAR,double,3>+query"
+    res = dict(name="cfg5_1gpu64_replay", desc=desc, model="angular_rates+uniform_acceleration", dtype="f64", targets_per_gpu=1_000_000,
+               layout="axis_separable_packed+axis_separable_packed", launch_mode="graph: one branch per batch, free-running inside blocks of ticks (replay only)",
+               cycles_per_s=6.8421052631578947e9, ms_per_step=0.14615384615384616, achieved_gbs=6012.345678901234, state_bytes=408123456,
+               residency="L3-assisted: state = 1.5 x the 256 MB Infinity Cache (zig-zag traversal reuses the part touched last)")
+    dom = dict(kernel=kern, model="angular_rates", units_per_launch=500_000, algorithmic_bytes_per_unit=968, avg_launch_ms=0.0802345678,
+               achieved_gbs=6031.23456789, traffic=484212345.678)
+    return bench, res, dom
+
+
+def test_the_line_is_short_enough_for_the_driver_to_parse():
+    """Round 2's line was 30 KB and the driver's bounded stdout tail did not hold it (BENCH_r02.json: parsed = null).  The
+    line now carries the contract's keys only; everything else goes to the side file."""
+    import argparse
+    bench, res, dom = _fake_result()
+    args = argparse.Namespace(steps=20, warmup=5, side_file="")
+    for world in (1, 8):
+        out = bench.make_line(args, res, dom, world, {"_meta": {"commit": "0123456789ab"}})
+        if world == 1:
+            out["cpu_baseline"] = dict(value=2.9e6, unit="cycles/s", cores=16, kind="port",
+                                       sample="10000 angular_rates x 12 ticks + 10000 angular_velocities x 31 ticks (f64, OpenMP static over "
+                                              "targets, -O3 -march=native rebuilt on this host)")
+            out["parity"] = bench.parity_summary(dict(targets_per_model=256, ticks=[1, 100, 1000], models={
+                "angular_rates": dict(max_abs_x=[1e-15, 4.9e-14, 3e-14], max_rel_P=[1e-16, 4.3e-15, 2e-15], ids_exact=True),
+                "angular_velocities": dict(max_abs_x=[1e-15, 1.1e-14, 1e-14], max_rel_P=[1e-16, 5.4e-15, 2e-15], ids_exact=True)}))
+        line = json.dumps(bench.compact_line(out))
+        assert len(line) + 1 < bench.LINE_LIMIT < 8192
+        back = json.loads(line)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline"):
+            assert k in back
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "algorithmic_bytes_per_unit", "units_per_launch",
+                  "avg_launch_ms", "traffic_source"):
+            assert k in back["roofline"]
+        assert "workload" in back["config"] and "side_file" in back["config"] and back["n_gpus"] == world
+        assert "extra" not in back and "kernels" not in back["roofline"]
+        if world == 1:
+            assert set(back["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"}
+
+
+def test_an_oversized_line_sheds_optional_keys_instead_of_breaking():
+    import argparse
+    bench, res, dom = _fake_result()
+    out = bench.make_line(argparse.Namespace(steps=20, warmup=5, side_file=""), res, dom, 1, {})
+    out["parity"] = "x" * 6000
+    line = bench.compact_line(out)
+    assert "parity" not in line and len(json.dumps(line)) < bench.LINE_LIMIT and line["value"] == pytest.approx(res["cycles_per_s"], rel=1e-5)
+
+
+def test_dry_run_lines_are_short():
+    for a in (["--dry-run"], ["--gpus", "2", "--dry-run"]):
+        p, line = _run(a + ["--steps", "4", "--warmup", "1"])
+        assert p.returncode == 0
+        assert all(len(ln) < 4096 for ln in p.stdout.splitlines())
+
+
 @pytest.mark.gpu
-def test_two_ranks_end_to_end_on_one_gpu():
+def test_two_ranks_end_to_end_on_one_gpu(tmp_path):
     """The literal `bench.py --gpus 2` (it starts its two ranks itself), gloo between them, both on the box's one GPU:
-    every rank steps its own shard, rank 0 prints the one line."""
+    every rank steps its own shard, rank 0 prints the one line (first) and writes the side file."""
+    side = str(tmp_path / "side.json")
     p, line = _run(["--gpus", "2", "--steps", "8", "--warmup", "2", "--reps", "2", "--workload", "cfg4_64", "--extra-multi", "uv1m_strong",
-                    "--extra-steps", "4"], env={"TE_BENCH_BACKEND": "gloo"}, timeout=600)
+                    "--extra-steps", "4", "--side-file", side], env={"TE_BENCH_BACKEND": "gloo"}, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["targets_total"] == 2 * line["config"]["targets_per_gpu"]
-    assert line["extra"][0]["name"] == "uv1m_strong" and line["extra"][0]["targets_per_gpu"] == 500_000
+    assert len(json.dumps(line)) < 4096 and "roofline" in line
+    extra = json.load(open(side))["extra"]
+    assert extra[0]["name"] == "uv1m_strong" and extra[0]["targets_per_gpu"] == 500_000
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_parses_and_carries_roofline_and_cpu_baseline(tmp_path):
+    """The driver's command shape at N = 1 (fewer extras, to keep the test short): the last stdout line is the record."""
+    side = str(tmp_path / "side.json")
+    p, line = _run(["--steps", "6", "--warmup", "2", "--reps", "2", "--extra", "cfg2,ar4m64", "--extra-steps", "4", "--side-file", side], timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    last = p.stdout.strip().splitlines()[-1]
+    assert len(last) < 4096 and json.loads(last) == line
+    assert line["config"]["name"] == "cfg4_1gpu" and line["dtype"] == "f64" and line["value"] > 1e7
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.0 < r["frac"] < 1.0
+    assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_unit"] * r["units_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9, rel=1e-3)
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1
+    sidej = json.load(open(side))
+    assert {e["name"] for e in sidej["extra"]} >= {"cfg2", "ar4m64"} and "configs0" in sidej and "parity" in sidej
+    rows = sidej["configs0"]["rows"]
+    assert [r["steps"] for r in rows] == [1000, 10000] and all(r["max_abs_pose_difference"] < 1e-9 for r in rows)

@@ -1,7 +1,16 @@
 """BASELINE.json configs[3] / configs[4] at their per-GPU size (62 500 + 62 500 targets, two motion models in one
 manager) through target_manager_step_sequence_all -- the call bench.py times -- against the ORACLE on a 2 000-target
 sample per model: state and covariance, and for configs[4] the fused per-tick sphere query's delta.  (Round 1 only
-compared this path with the library's own per-batch calls.)"""
+compared this path with the library's own per-batch calls.)
+
+Round 3: the same call at the HEADLINE's own size and schedule -- bench.py's `value` is cfg4_1gpu = 500 000 + 500 000 fp64
+targets through the EAGER target_manager_step_sequence_all, whose all-batches zig-zag (batch order and tile order reversed
+on odd ticks, csrc/target_manager.cpp stepSequenceAll; reference semantics: the caller's loop over every target every
+tick, src/target_manager.cpp:190-225) is only taken from 128 MB of state.  The oracle regenerates the measurement stream
+itself (oracle.stream_sample, the CPU twin of the library's keyed generator): nothing is copied back but the results."""
+import os
+import subprocess
+import sys
 import numpy as np
 import pytest
 
@@ -20,7 +29,7 @@ def _build(models, parts, dtype, ticks, dt, seed, accel_scene=False):
     base, out = 0, []
     for k, (name, n) in enumerate(parts):
         m = models[name]
-        st = make_stream(te.MODEL_TYPES[name], n, ticks, dt, seed + 17 * k)
+        st = make_stream(te.MODEL_TYPES[name], n, ticks, dt, seed + 17 * k, dtype=dtype)
         ids = np.arange(n, dtype=np.uint32) + base
         base += n
         p0 = st["p0"].cpu().numpy()
@@ -31,11 +40,24 @@ def _build(models, parts, dtype, ticks, dt, seed, accel_scene=False):
             v0 = np.concatenate([-d * rng.uniform(1, 6, (n, 1)), np.zeros((n, 3))], 1)
             a0 = np.concatenate([rng.normal(0, 1.0, (n, 3)) + [0, 0, -2.0], np.zeros((n, 3))], 1)
         assert mgr.init_batch(ids, dt, 0.0, p0, v0, a0, type=te.MODEL_TYPES[name], Q=m["Q"], R=m["R"], P0=m["P"]) == n
-        out.append(dict(name=name, ids=ids, p0=p0, v0=v0, a0=a0, meas64=st["meas"]))
+        out.append(dict(name=name, ids=ids, p0=p0, v0=v0, a0=a0, meas=st["meas"], seed=seed + 17 * k))
     batches = mgr.batches()
     assert len(batches) == len(parts)
-    meas = [o["meas64"].to(b.torch_dtype()).contiguous() for o, b in zip(out, batches)]
+    meas = [o["meas"] for o in out]
+    assert all(m.dtype == b.torch_dtype() for m, b in zip(meas, batches))
     return mgr, batches, out, meas
+
+
+def _oracle_on_sample(models, o, sample, ticks, dt, dtype):
+    """The oracle over `sample` (indices into the batch) for `ticks` ticks, on the stream it regenerates itself."""
+    m = models[o["name"]]
+    ref = oracle.stream_sample(m["model"], o["seed"], sample, ticks, dt, dtype=dtype)
+    np.testing.assert_array_equal(ref["p0"][:, :3], o["p0"][sample][:, :3])     # same keyed stream on both sides
+    orc = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], o["p0"][sample], dt, 0.0,
+                             None if o["v0"] is None else o["v0"][sample], None if o["a0"] is None else o["a0"][sample], dtype=dtype)
+    for s in range(ticks):
+        orc.step(dt, ref["meas"][s])
+    return orc
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
@@ -54,10 +76,7 @@ def test_config3_share_matches_oracle(models, dtype, use_graph):
         m = models[o["name"]]
         n = len(o["ids"])
         sample = np.sort(np.random.default_rng(1).choice(n, 2000, replace=False))
-        orc = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], o["p0"][sample], dt, dtype=dtype)
-        mh = mm[:, :, torch.from_numpy(sample).cuda()].to(torch.float64).cpu().numpy()     # what the kernel saw
-        for s in range(ticks):
-            orc.step(dt, np.ascontiguousarray(mh[s].T))
+        orc = _oracle_on_sample(models, o, sample, ticks, dt, dtype)
         check_state(mgr, o["ids"][sample], orc, dtype, "%s sample of configs[3]" % o["name"])
         np.testing.assert_array_equal(b.slot_ids()[::997], o["ids"][::997])
         assert mgr.getNumberMeasurements(int(o["ids"][-1])) == ticks
@@ -82,10 +101,7 @@ def test_config4_share_with_fused_query_matches_oracle(models, dtype):
         m = models[o["name"]]
         n = len(o["ids"])
         sample = np.sort(np.random.default_rng(2).choice(n, 2000, replace=False))
-        orc = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], o["p0"][sample], dt, 0.0, o["v0"][sample], o["a0"][sample], dtype=dtype)
-        mh = mm[:, :, torch.from_numpy(sample).cuda()].to(torch.float64).cpu().numpy()
-        for s in range(ticks):
-            orc.step(dt, np.ascontiguousarray(mh[s].T))
+        orc = _oracle_on_sample(models, o, sample, ticks, dt, dtype)
         check_state(mgr, o["ids"][sample], orc, dtype, "%s sample of configs[4]" % o["name"])
         ok_o, pose_o, delta_o = orc.intersection_pose(ticks * dt, origin, radius)
         d = dd.cpu().numpy()[sample]
@@ -98,3 +114,94 @@ def test_config4_share_with_fused_query_matches_oracle(models, dtype):
         n_hit += int(both.sum())
     assert n_hit > 200       # the scene has intersections to find
     mgr.close()
+
+
+def _check_query(dd, pp, sample, orc, t_now, origin, radius, dtype):
+    ok_o, pose_o, delta_o = orc.intersection_pose(t_now, origin, radius)
+    d = dd.cpu().numpy()[sample]
+    hit, hit_o = d > -1, delta_o > -1
+    assert (hit != hit_o).mean() <= (0.0 if dtype == "f64" else 0.01)
+    both = hit & hit_o
+    rtol = 1e-8 if dtype == "f64" else 5e-4
+    np.testing.assert_allclose(d[both], delta_o[both], rtol=rtol, atol=rtol)
+    np.testing.assert_allclose(pp.cpu().numpy()[sample][both], pose_o[both], atol=1e-7 if dtype == "f64" else 1e-2)
+    return int(both.sum())
+
+
+@pytest.mark.parametrize("wl", ["cfg4_1gpu", "cfg5_1gpu", "cfg5_1gpu64"])
+def test_headline_path_at_full_size_matches_oracle(models, wl):
+    """bench.py's headline workload as bench.py runs it: 10^6 targets in two batches, ONE eager
+    target_manager_step_sequence_all call for an odd number of ticks (5), so that both traversal directions and both batch
+    orders of the manager-level zig-zag run; 2 000-target sample per model against the oracle (state, covariance, and for
+    configs[4] the fused query's delta / pose after the last tick)."""
+    import bench
+    desc, parts, dtype, seed, intersect = bench.MIXED[wl]
+    ticks, dt = 5, 0.004
+    origin, radius = np.zeros(3), 5.0
+    mgr, batches, info, meas = _build(models, parts, dtype, ticks, dt, seed, accel_scene=intersect)
+    state = sum(b.resident_bytes_per_target * b.size for b in batches)
+    assert state >= 128 << 20, "below the zig-zag threshold: this test would not cover the headline's branch"
+    query = None
+    if intersect:
+        deltas = [torch.full((b.size,), 123.0, dtype=torch.float64, device="cuda") for b in batches]
+        poses = [torch.zeros((b.size, 7), dtype=torch.float64, device="cuda") for b in batches]
+        query = (origin, radius, deltas, poses)
+    mgr.step_sequence_all(dt, meas, query=query, use_graph=0)          # the bench's call: eager, all ticks in one call
+    torch.cuda.synchronize()
+    n_hit = 0
+    for j, (o, b) in enumerate(zip(info, batches)):
+        n = len(o["ids"])
+        sample = np.sort(np.random.default_rng(3 + j).choice(n, 2000, replace=False))
+        sample[0], sample[-1] = 0, n - 1                                 # first and last tile in both directions
+        orc = _oracle_on_sample(models, o, sample, ticks, dt, dtype)
+        check_state(mgr, o["ids"][sample], orc, dtype, "%s sample of %s" % (o["name"], wl))
+        if intersect:
+            n_hit += _check_query(deltas[j], poses[j], sample, orc, ticks * dt, origin, radius, dtype)
+        np.testing.assert_array_equal(b.slot_ids()[::9973], o["ids"][::9973])
+        assert mgr.getNumberMeasurements(int(o["ids"][-1])) == ticks and mgr.getNumberMeasurements(int(o["ids"][0])) == ticks
+    if intersect:
+        assert n_hit > 200
+    # a second call continues the alternation where the first one stopped (odd tick count): still the oracle's result
+    mgr.step_sequence_all(dt, [m[:2] for m in meas], query=query, use_graph=0)
+    torch.cuda.synchronize()
+    o, b = info[0], batches[0]
+    sample = np.arange(0, len(o["ids"]), len(o["ids"]) // 500)[:500]
+    m = models[o["name"]]
+    ref = oracle.stream_sample(m["model"], o["seed"], sample, ticks, dt, dtype=dtype)
+    orc = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], o["p0"][sample], dt, 0.0,
+                             None if o["v0"] is None else o["v0"][sample], None if o["a0"] is None else o["a0"][sample], dtype=dtype)
+    for s in list(range(ticks)) + [0, 1]:
+        orc.step(dt, ref["meas"][s])
+    check_state(mgr, o["ids"][sample], orc, dtype, "%s after the second call of %s" % (o["name"], wl))
+    mgr.close()
+
+
+def _zigzag_small_case():
+    """Run in a child process with TE_ZIGZAG_MIN_MB=0 (the threshold is read once per process): three small batches, ragged
+    last tiles, the manager-level zig-zag (eager all-batches call) and the per-batch zig-zag (step_sequence), against the
+    oracle on EVERY target."""
+    import yaml  # noqa: F401
+    from conftest import MODEL_FILES, model_path
+    models = {k: oracle.load_model_yaml(model_path(k)) for k in MODEL_FILES}
+    assert os.environ.get("TE_ZIGZAG_MIN_MB") == "0"
+    for dtype in ("f64", "f32"):
+        parts = [("uniform_velocity", 777), ("angular_rates", 333), ("uniform_acceleration", 1501)]
+        ticks, dt = 7, 0.004
+        mgr, batches, info, meas = _build(models, parts, dtype, ticks, dt, 4242)
+        mgr.step_sequence_all(dt, [m[:5] for m in meas], use_graph=0)                       # manager-level zig-zag, odd count
+        for b, m in zip(batches, meas):
+            b.step_sequence(dt, m[5:7], None, use_graph=False)                               # per-batch zig-zag
+        torch.cuda.synchronize()
+        for o in info:
+            sample = np.arange(len(o["ids"]))
+            orc = _oracle_on_sample(models, o, sample, ticks, dt, dtype)
+            check_state(mgr, o["ids"], orc, dtype, "%s, zig-zag forced on a small batch" % o["name"])
+        mgr.close()
+    print("zigzag small case ok")
+
+
+def test_zigzag_forced_on_small_batches_matches_oracle():
+    env = dict(os.environ, TE_ZIGZAG_MIN_MB="0", PYTHONPATH=os.pathsep.join([os.path.dirname(__file__), os.path.dirname(os.path.dirname(__file__))]))
+    p = subprocess.run([sys.executable, "-c", "import test_gpu_mixed_configs as t; t._zigzag_small_case()"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "zigzag small case ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
