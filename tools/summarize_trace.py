@@ -11,6 +11,7 @@ from collections import defaultdict
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*", "", name)
     return name.replace("void ", "").replace("te::", "")
 
