@@ -193,7 +193,9 @@ int target_batch_step_sequence_ring(target_batch_c* b, long n_ticks, double dt, 
                                     const unsigned char* has_meas_dev, long has_stride, long ring_ticks, int use_graph);
 /* The same n_ticks ticks in ONE launch: each target's state stays in registers across the ticks and
  * only the measurements are read per tick (temporal fusion; identical results).  For replaying
- * recorded streams; its throughput is an "effective" figure, not comparable with one launch per tick. */
+ * recorded streams; its throughput is an "effective" figure, not comparable with one launch per tick.
+ * Batches that have no fused kernel -- several (Q, R) classes in the batch, or one of the few (model, precision, layout)
+ * combinations whose fused form would spill -- are served tick by tick inside the call: same results, one launch per tick. */
 int target_batch_step_fused(target_batch_c* b, long n_ticks, double dt, const void* meas_dev, long tick_stride, long ld,
                             const unsigned char* has_meas_dev, long has_stride);
 /* n_ticks ticks of EVERY batch of the manager in one call (BASELINE.json configs[3]/[4]: several motion

@@ -89,7 +89,7 @@ Batch::~Batch() {
   (void)hipStreamSynchronize(stream_);
   drop_graphs();
   if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
-  (void)hipFree(d_qr_); (void)hipFree(d_rec_); (void)hipFree(d_tbase_); (void)hipFree(d_nmbase_); (void)hipFree(d_cls_);
+  (void)hipFree(d_qr_); (void)hipFree(d_rec_); (void)hipFree(d_rec_alt_); (void)hipFree(d_tbase_); (void)hipFree(d_nmbase_); (void)hipFree(d_cls_);
   (void)hipFree(d_idx_); (void)hipFree(d_aos_); (void)hipFree(d_meas_); (void)hipFree(d_mask_); (void)hipFree(d_P0_);
   (void)hipFree(d_gate_ring_); (void)hipFree(d_gate_sum_); (void)hipFree(d_gate_state_); (void)hipFree(d_gate_prev_);
   (void)hipFree(d_dtper_);
@@ -101,6 +101,20 @@ Batch::~Batch() {
 long Batch::zigzag_min_bytes() {
   static const long v = [] { const char* e = std::getenv("TE_ZIGZAG_MIN_MB"); return (e ? std::atol(e) : 128L) << 20; }();
   return v;
+}
+
+long Batch::pingpong_min_bytes() {
+  static const long v = [] { const char* e = std::getenv("TE_PINGPONG_MIN_MB"); const long mb = e ? std::atol(e) : 1536L; return mb < 0 ? -1L : mb << 20; }();
+  return v;
+}
+
+char* Batch::alt_records() {
+  if (!d_rec_alt_) {   // same capacity as d_rec_; zero-filled so that the idle lanes of a ragged last tile hold defined words
+    const size_t bytes = (size_t)(cap_ / ops_->L.tpw) * (size_t)ops_->L.tile_bytes;
+    TE_HIP_CHECK(hipMalloc((void**)&d_rec_alt_, bytes));
+    TE_HIP_CHECK(hipMemsetAsync(d_rec_alt_, 0, bytes, stream_));
+  }
+  return d_rec_alt_;
 }
 
 void Batch::synchronize() {
@@ -153,6 +167,7 @@ void Batch::reserve(long n) {
   }
   TE_HIP_CHECK(hipStreamSynchronize(stream_));
   (void)hipFree(d_rec_); (void)hipFree(d_tbase_); (void)hipFree(d_nmbase_); (void)hipFree(d_cls_);
+  (void)hipFree(d_rec_alt_); d_rec_alt_ = nullptr;   // re-created at the new capacity by the next A -> B tick
   d_rec_ = rec; d_tbase_ = tb; d_nmbase_ = nm; d_cls_ = cl; cap_ = want;
   drop_graphs();
 }
@@ -280,7 +295,9 @@ void Batch::step_dense(double dt, const void* meas_dev, long ld, const unsigned 
   p.meas = meas_dev; p.meas_ld = ld; p.has_meas = has_dev; p.dt = dt;
   p.reverse = (flip_ && zigzag()) ? 1 : 0;   // zig-zag: consecutive dense ticks walk the tiles in opposite directions
   flip_ = !flip_;
+  if (pingpong()) p.rec_out = alt_records();
   ops_->step(p, stream_);
+  if (p.rec_out) std::swap(d_rec_, d_rec_alt_);   // later launches on the stream see the finished tick in the new current buffer
   t_acc_ += dt;
   if (meas_dev && !has_dev) nm_acc_ += 1;
 }
@@ -306,7 +323,13 @@ void Batch::step_sequence(long n_ticks, double dt, const void* meas_base, long t
     return p;
   };
   if (!use_graph) {
-    for (long s = 0; s < n_ticks; ++s) ops_->step(params(s), stream_);
+    const bool ab = pingpong();
+    for (long s = 0; s < n_ticks; ++s) {
+      StepParams p = params(s);
+      if (ab) p.rec_out = alt_records();
+      ops_->step(p, stream_);
+      if (ab) std::swap(d_rec_, d_rec_alt_);
+    }
     TE_HIP_CHECK(hipGetLastError());
     if (n_ticks & 1) flip_ = !flip_;
   } else {
@@ -358,7 +381,7 @@ void Batch::step_sequence(long n_ticks, double dt, const void* meas_base, long t
 }
 
 void Batch::enqueue_tick(hipStream_t st, long s, double dt, const SeqSpec& q, bool query, const double* origin, double radius,
-                         bool reverse) {
+                         bool reverse, bool ab) {
   if (n_ == 0) return;
   if (q.ring_ticks > 0) s %= q.ring_ticks;
   const size_t es = elem_size();
@@ -373,7 +396,9 @@ void Batch::enqueue_tick(hipStream_t st, long s, double dt, const SeqSpec& q, bo
     p.q_origin[0] = origin[0]; p.q_origin[1] = origin[1]; p.q_origin[2] = origin[2];
     p.q_radius = radius; p.q_delta = q.delta_dev; p.q_pose = q.pose_dev;
   }
+  if (ab) p.rec_out = alt_records();
   ops_->step(p, st);
+  if (ab) std::swap(d_rec_, d_rec_alt_);
   if (query && !fused_q) {
     IntersectArgs a;
     a.rec = d_rec_; a.idx = nullptr; a.n = n_; a.t1 = std::numeric_limits<double>::quiet_NaN();

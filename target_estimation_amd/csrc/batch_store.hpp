@@ -132,8 +132,10 @@ class Batch {
   };
   // tick s of the spec on `st`, without touching the batch clock.  With query: the own-time sphere
   // query of every slot runs inside the step kernel (one launch).
+  // ab: 1 = an A -> B tick (records read from the current buffer, written to the alternate one, buffers swapped; never
+  // inside a stream capture: a recorded graph bakes its pointers), 0 = in place.
   void enqueue_tick(hipStream_t st, long s, double dt, const SeqSpec& spec, bool query, const double* origin, double radius,
-                    bool reverse = false);
+                    bool reverse = false, bool ab = false);
   void account_sequence(long n_ticks, double dt, bool all_measured);
   // identity of everything a recorded launch sequence refers to
   struct DevIdentity { const void* rec; const void* qr; const void* tbase; const void* nmbase; long n; };
@@ -152,6 +154,11 @@ class Batch {
   long algorithmic_bytes_per_cycle() const;
   long state_bytes() const { return (n_ + ops_->L.tpw - 1) / ops_->L.tpw * ops_->L.tile_bytes; }
   static long zigzag_min_bytes();   // default 128 MB (env TE_ZIGZAG_MIN_MB)
+  // A -> B ticks with nontemporal stores (kf_step.hpp StepArgs::rec_out) instead of in-place read-modify-write: the policy of
+  // eager dense ticks once the state is this large (default 1536 MB, env TE_PINGPONG_MIN_MB; a negative value switches it off).
+  // Below it the zig-zag in place wins (the Infinity Cache still holds a useful share of the state); costs a second record buffer.
+  static long pingpong_min_bytes();
+  bool pingpong() const { return pingpong_min_bytes() >= 0 && state_bytes() >= pingpong_min_bytes(); }
   char* records_dev() const { return d_rec_; }
 
  private:
@@ -172,7 +179,9 @@ class Batch {
   // walked backwards lands on another XCD, whose L2 does not hold it (10^5 UA fp32: 4.7 -> 8.2 us per tick).
   bool zigzag() const { return state_bytes() >= zigzag_min_bytes(); }
   StepParams base_params() const;
-  char* d_rec_ = nullptr;
+  char* d_rec_ = nullptr;          // the CURRENT records (A -> B ticks swap it with d_rec_alt_ after every launch)
+  char* d_rec_alt_ = nullptr;      // second record buffer of the same capacity, allocated on the first A -> B tick
+  char* alt_records();
   double* d_tbase_ = nullptr;
   int* d_nmbase_ = nullptr;
   long cap_ = 0;  // slots

@@ -11,6 +11,7 @@ namespace te {
 
 struct StepParams {
   char* rec;
+  char* rec_out = nullptr;        // dense single-tick launches: write the records here instead of in place (StepArgs::rec_out)
   const void* qr;                 // one [Q | R] block, or (cls != null) a table of them
   const int* cls = nullptr;       // per-slot parameter class: selects the per-class kernels
   long n;

@@ -18,7 +18,7 @@ struct OpsImpl {
   static void step(const StepParams& p, hipStream_t s) {
     if (p.n <= 0) return;
     StepArgs<T> a;
-    a.rec = p.rec; a.qr = static_cast<const T*>(p.qr); a.cls = p.cls; a.n = p.n; a.idx = p.idx;
+    a.rec = p.rec; a.rec_out = p.rec_out; a.qr = static_cast<const T*>(p.qr); a.cls = p.cls; a.n = p.n; a.idx = p.idx;
     a.meas = static_cast<const T*>(p.meas); a.meas_ld = p.meas_ld; a.has_meas = p.has_meas;
     a.dt_per = p.dt_per; a.dt = p.dt; a.t_base = p.t_base; a.nm_base = p.nm_base;
     a.n_ticks = p.n_ticks; a.tick_stride = p.tick_stride; a.has_stride = p.has_stride;
@@ -38,13 +38,15 @@ struct OpsImpl {
     const int wpb_dense = waves <= small_grid ? 1 : C::WPB;
     const unsigned blocks = (unsigned)((waves + wpb_dense - 1) / wpb_dense);
     if (p.n_ticks > 1 && p.idx) throw std::runtime_error("target_estimation_amd: fused multi-tick launches are dense only");
+    if (p.rec_out && (p.idx || p.n_ticks > 1)) throw std::runtime_error("target_estimation_amd: A -> B ticks are dense single-tick launches");
     // A few temporally fused instantiations do not fit the register file and would spill hundreds of bytes per lane to
     // scratch (228 / 116 / 340 / 352 B): for them a fused request is served tick by tick -- same results.
     constexpr bool kFusedSpills = (M::TYPE == ANGULAR_RATES && sizeof(T) == 8 && G == 3 && LAYOUT == LAYOUT_PACKED) ||
                                   (M::TYPE == ANGULAR_VELOCITIES && sizeof(T) == 4 && G == 1 && LAYOUT == LAYOUT_FULL) ||
                                   (M::TYPE == ANGULAR_VELOCITIES && sizeof(T) == 8 && G == 1 && LAYOUT == LAYOUT_PACKED) ||
                                   (M::TYPE == ANGULAR_RATES && sizeof(T) == 8 && G == 6 && LAYOUT == LAYOUT_PACKED);
-    if (kFusedSpills && p.n_ticks > 1) {
+    // A batch with several (Q, R) classes has no temporally fused kernel either: same tick-by-tick service (same results).
+    if ((kFusedSpills || p.cls) && p.n_ticks > 1) {
       StepParams q = p;
       q.n_ticks = 1;
       for (int t = 0; t < p.n_ticks; ++t) {
@@ -54,8 +56,8 @@ struct OpsImpl {
       }
       return;
     }
-    if (p.cls && (p.n_ticks > 1 || p.q_delta))
-      throw std::runtime_error("target_estimation_amd: a batch with several (Q, R) classes steps one tick per launch, without the fused query");
+    if (p.cls && p.q_delta)
+      throw std::runtime_error("target_estimation_amd: a batch with several (Q, R) classes has no fused sphere query (step, then target_batch_intersect_sphere_dev)");
     if constexpr (C::SEP) {
       // small (latency-bound) grids: one wavefront per workgroup spreads the waves over more CUs
       const int wpb = waves <= small_grid ? 1 : 4;

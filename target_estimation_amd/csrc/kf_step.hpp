@@ -33,6 +33,13 @@ namespace te {
 template <typename T>
 struct StepArgs {
   char* rec;                 // lane records, tile-major (te_layout.hpp)
+  // A -> B ("ping-pong") ticks: rec_out != null makes a dense launch read every record from `rec` and write it, with
+  // nontemporal stores, to the same place in `rec_out` (a second buffer of the same layout; the batch swaps the two after the
+  // launch).  Once the state is several times the 256 MB Infinity Cache nothing of a tick survives to the next one anyway,
+  // and keeping reads and writes in separate address streams -- writes that allocate nowhere on their way -- moves more
+  // bytes per second than read-modify-write in place (profiles/r02_rmw_ceiling.txt: 1.9 GB of state 5.30 -> 5.74 TB/s).
+  // Same arithmetic, same results.  null: in place.
+  char* rec_out;
   const T* qr;               // Q (N*N row-major) then R (K*K row-major), compute precision; PERQR: a table of such blocks
   const int* cls;            // PERQR only: parameter class of slot s (its block of the qr table)
   long n;                    // dense: number of targets; indexed: number of entries
@@ -111,7 +118,7 @@ __device__ __forceinline__ void load_record(const char* tb, int lane, T* rec) {
   if constexpr (C::REM1) rec[C::RW - 1] = *reinterpret_cast<const T*>(tb + C::TAIL1_OFF + (long)lane * (long)sizeof(T));
 }
 
-template <class C, typename T, bool OPAQUE = false>
+template <class C, typename T, bool OPAQUE = false, bool NT = false>
 __device__ __forceinline__ void store_record(char* tb, int lane, const T* rec) {
   using V = typename Vec16<T>::type;
 #pragma unroll
@@ -122,7 +129,14 @@ __device__ __forceinline__ void store_record(char* tb, int lane, const T* rec) {
       else { v.x = opaque_copy(rec[c * 4]); v.y = opaque_copy(rec[c * 4 + 1]); v.z = opaque_copy(rec[c * 4 + 2]); v.w = opaque_copy(rec[c * 4 + 3]); }
     } else if constexpr (sizeof(T) == 8) { v.x = rec[c * 2]; v.y = rec[c * 2 + 1]; }
     else { v.x = rec[c * 4]; v.y = rec[c * 4 + 1]; v.z = rec[c * 4 + 2]; v.w = rec[c * 4 + 3]; }
-    *reinterpret_cast<V*>(tb + (long)c * C::LPT * 16 + (long)lane * 16) = v;
+    if constexpr (NT) {   // the builtin takes native vectors, not HIP's wrapper types
+      typedef float nt4 __attribute__((ext_vector_type(4)));
+      nt4 raw;
+      __builtin_memcpy(&raw, &v, 16);
+      __builtin_nontemporal_store(raw, reinterpret_cast<nt4*>(tb + (long)c * C::LPT * 16 + (long)lane * 16));
+    } else {
+      *reinterpret_cast<V*>(tb + (long)c * C::LPT * 16 + (long)lane * 16) = v;
+    }
     if constexpr (OPAQUE) {
       if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
@@ -699,7 +713,12 @@ kf_step_kernel(const StepArgs<T> a) {
 #pragma unroll
       for (int w = 0; w < C::RW; ++w) mem[w] = rec[w];
     }
-    store_record<C, T, EKF_SYM>(tb, lt, mem);
+    if constexpr (!INDEXED) {
+      if (a.rec_out != nullptr) store_record<C, T, EKF_SYM, true>(a.rec_out + tile * C::TILE_BYTES, lt, mem);   // A -> B tick (StepArgs::rec_out)
+      else store_record<C, T, EKF_SYM>(tb, lt, mem);
+    } else {
+      store_record<C, T, EKF_SYM>(tb, lt, mem);
+    }
     if (i == 0) {
       if constexpr (INDEXED) {
         const long slot = slot_of;

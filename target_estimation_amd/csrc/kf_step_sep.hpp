@@ -465,7 +465,12 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR>())) k
 
   }  // tick loop
   if (valid) {
-    store_record<C, T>(tb, lt, mem);
+    if constexpr (!INDEXED) {
+      if (a.rec_out != nullptr) store_record<C, T, false, true>(a.rec_out + tile * C::TILE_BYTES, lt, mem);   // A -> B tick (StepArgs::rec_out)
+      else store_record<C, T>(tb, lt, mem);
+    } else {
+      store_record<C, T>(tb, lt, mem);
+    }
     if constexpr (QUERY) {
       T xq[N];
 #pragma unroll

@@ -952,11 +952,14 @@ void TargetManager::stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpe
     long state = 0;
     for (size_t b = 0; b < nb; ++b) state += batches_[b]->state_bytes();
     const bool zz = state >= Batch::zigzag_min_bytes();   // L2-resident populations keep their tile -> XCD affinity
+    // A -> B ticks (Batch::pingpong_min_bytes) by the size of the WHOLE population: what decides is how much is streamed
+    // between two uses of a record, not which batch it belongs to
+    const bool ab = Batch::pingpong_min_bytes() >= 0 && state >= Batch::pingpong_min_bytes();
     for (long s = 0; s < n_ticks; ++s) {
       const bool rev = zz && seq_flip_;
       for (size_t k = 0; k < nb; ++k) {
         const size_t b = rev ? nb - 1 - k : k;
-        batches_[b]->enqueue_tick(stream_, s, dt, specs[b], query, org, radius, rev);
+        batches_[b]->enqueue_tick(stream_, s, dt, specs[b], query, org, radius, rev, ab);
       }
       seq_flip_ = !seq_flip_;
     }

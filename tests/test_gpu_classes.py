@@ -177,3 +177,41 @@ def test_one_at_a_time_inits_join_one_batch(models):
     np.testing.assert_array_equal(P[0], P[3])
     assert np.abs(P[0] - P[1]).max() > 0
     mgr.close()
+
+
+@pytest.mark.parametrize("name,dtype,coupled", [("uniform_velocity", "f64", False), ("angular_rates", "f32", False), ("uniform_acceleration", "f64", True)])
+def test_step_fused_on_a_batch_with_several_classes(models, name, dtype, coupled):
+    """A second (Q, R) for a model joins the model's batch as a class; the temporally fused multi-tick call on such a batch is
+    served tick by tick (there is no per-class fused kernel) with the results of single ticks -- it used to throw after the
+    queue had already been flushed (round-2 advisor finding).  Against one oracle per class."""
+    m = models[name]
+    N, dt, ticks = 500, 0.004, 6
+    rng = np.random.default_rng(21)
+    Q, R, P0 = (_coupled_classes if coupled else _scaled_classes)(m, 2, rng)
+    class_of = (np.arange(N) % 2).astype(np.uint32)
+    ref = oracle.stream_fill(m["model"], 31, N, ticks, dt, dtype=dtype)
+    from target_estimation_amd.streams import make_stream
+    st = make_stream(m["model"], N, ticks, dt, 31, dtype=dtype)
+    ids = np.arange(N, dtype=np.uint32)
+    mgr = te.TargetManager(dtype=dtype)
+    assert mgr.init_batch_classes(ids, dt, 0.0, ref["p0"], m["model"], Q, R, P0, class_of) == N
+    b = mgr.batches()[0]
+    assert len(mgr.batches()) == 1 and b.num_classes == 2
+    mgr.update(3, dt, ref["meas"][0, 3])          # a queued one-target step must survive the call, too
+    b.step_fused(dt, st["meas"])                  # 6 ticks "in one call": tick by tick for a multi-class batch
+    members = {c: np.nonzero(class_of == c)[0] for c in (0, 1)}
+    orcs = {}
+    for c, rows in members.items():
+        orc = oracle.OracleBatch(m["model"], Q[c], R[c], P0[c], ref["p0"][rows], dt, dtype=dtype)
+        if c == 1:
+            hit = np.zeros(len(rows), dtype=np.uint8); hit[list(rows).index(3)] = 1
+            for i in np.nonzero(hit)[0]:
+                import ctypes as C
+                row = np.ascontiguousarray(ref["meas"][0, 3])
+                orc._f("orc_target_add_measurement")(orc._at(int(i)), float(dt), row.ctypes.data_as(C.POINTER(C.c_double)))
+        for s in range(ticks):
+            orc.step(dt, ref["meas"][s][rows])
+        orcs[c] = orc
+    _check_classes(mgr, orcs, ids, members, dtype, "%s fused call on two classes" % name)
+    assert mgr.getNumberMeasurements(0) == ticks and mgr.getNumberMeasurements(3) == ticks + 1
+    mgr.close()

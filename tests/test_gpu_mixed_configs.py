@@ -205,3 +205,124 @@ def test_zigzag_forced_on_small_batches_matches_oracle():
     p = subprocess.run([sys.executable, "-c", "import test_gpu_mixed_configs as t; t._zigzag_small_case()"], env=env,
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "zigzag small case ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
+def _pingpong_small_case():
+    """Child process with TE_PINGPONG_MIN_MB=0: every eager dense tick is an A -> B tick (records read from one buffer,
+    written with nontemporal stores to the other, buffers swapped).  Interleaved with everything that touches the CURRENT
+    buffer in place -- one-target calls, by-id batches, erase, creation beyond the capacity (reallocation), predict-only
+    ticks, the dense kernels of coupled matrices -- and compared with the oracle on every target."""
+    from conftest import MODEL_FILES, model_path
+    models = {k: oracle.load_model_yaml(model_path(k)) for k in MODEL_FILES}
+    assert os.environ.get("TE_PINGPONG_MIN_MB") == "0"
+    rng = np.random.default_rng(5)
+    for dtype in ("f64", "f32"):
+        for name, coupled in (("angular_rates", False), ("angular_velocities", False), ("uniform_acceleration", True), ("angular_rates", True)):
+            m = models[name]
+            Q, R, P0 = m["Q"], m["R"], m["P"]
+            if coupled:   # coupled symmetric matrices -> the dense kernels (kf_step.hpp) take the A -> B path too
+                def spd(A, s):
+                    B = rng.normal(size=A.shape) * s
+                    d = np.sqrt(np.diag(A))
+                    return A + (B @ B.T) * np.outer(d, d)
+                Q, R, P0 = spd(Q, 0.3), spd(R, 0.3), spd(P0, 0.3)
+            N, ticks, dt = 333, 9, 0.004
+            ref = oracle.stream_fill(m["model"], 77, N + 200, ticks, dt, dtype=dtype)
+            from target_estimation_amd.streams import make_stream
+            st = make_stream(m["model"], N + 200, ticks, dt, 77, dtype=dtype)
+            ids = np.arange(N, dtype=np.uint32) + 10
+            mgr = te.TargetManager(dtype=dtype)
+            mgr.init_batch(ids, dt, 0.0, ref["p0"][:N], type=m["model"], Q=Q, R=R, P0=P0)
+            b = mgr.batches()[0]
+            orc = oracle.OracleBatch(m["model"], Q, R, P0, ref["p0"][:N], dt, dtype=dtype)
+            meas = st["meas"]
+            mgr.step_sequence_all(dt, [meas[0:3, :, :N].contiguous()], use_graph=0)        # 3 A -> B ticks (odd: ends in the other buffer)
+            for s in range(3):
+                orc.step(dt, ref["meas"][s, :N])
+            check_state(mgr, ids, orc, dtype, "%s after the all-batches call" % name)
+            b.step(dt, meas[3, :, :N].contiguous())                                        # one A -> B tick
+            orc.step(dt, ref["meas"][3, :N])
+            mgr.update(int(ids[5]), dt, ref["meas"][4, 5])                                  # one-target call: in place, current buffer
+            mgr.update(int(ids[6]), dt)
+            one = oracle.OracleBatch(m["model"], Q, R, P0, ref["p0"][:N], dt, dtype=dtype)   # oracle per target: replay target 5 / 6
+            b.step_sequence(dt, meas[5:7, :, :N].contiguous(), None, use_graph=False)      # two more A -> B ticks
+            b.step(dt, None)                                                               # predict only
+            # the oracle, target by target, in the same order of operations
+            mask5 = np.zeros(N, dtype=np.uint8); mask5[5] = 1
+            mask6 = np.zeros(N, dtype=np.uint8); mask6[6] = 1
+            del one
+            _step_subset(orc, dt, ref["meas"][4, :N], mask5, predict_others=False)
+            _step_subset(orc, dt, None, mask6, predict_others=False)
+            for s in (5, 6):
+                orc.step(dt, ref["meas"][s, :N])
+            orc.step(dt, None)
+            check_state(mgr, ids, orc, dtype, "%s after in-place calls between A -> B ticks" % name)
+            # growth beyond the capacity reallocates the records (and drops the alternate buffer)
+            more = np.arange(200, dtype=np.uint32) + 5000
+            mgr.init_batch(more, dt, 0.0, ref["p0"][N:], type=m["model"], Q=Q, R=R, P0=P0)
+            assert mgr.erase(int(ids[0]))
+            b.step(dt, None)
+            keep = np.concatenate([ids[1:], more])
+            orc2 = oracle.OracleBatch(m["model"], Q, R, P0, ref["p0"][N:], dt, dtype=dtype)
+            orc2.step(dt, None)
+            orc.step(dt, None)
+            x, P = mgr.get_state_batch(keep)
+            xo, Po = orc.state(); xn, Pn = orc2.state()
+            xo, Po = np.concatenate([xo[1:], xn]), np.concatenate([Po[1:], Pn])
+            tol = 1e-9 if dtype == "f64" else 2e-3
+            assert np.abs(x - xo).max() <= tol * (1 + np.abs(xo).max()), (name, dtype)
+            assert (np.abs(P - Po).max(axis=(1, 2)) <= tol * np.abs(Po).max(axis=(1, 2))).all(), (name, dtype)
+            mgr.close()
+    print("pingpong small case ok")
+
+
+def _step_subset(orc, dt, meas, mask, predict_others):
+    """Step only the oracle targets whose mask byte is set (with `meas` or, if None, predict-only); the others stay."""
+    import ctypes as C
+    f_add = orc._f("orc_target_add_measurement")
+    f_upd = orc._f("orc_target_update")
+    for i in np.nonzero(mask)[0]:
+        if meas is None:
+            f_upd(orc._at(int(i)), float(dt))
+        else:
+            row = np.ascontiguousarray(meas[i], dtype=np.float64)
+            f_add(orc._at(int(i)), float(dt), row.ctypes.data_as(C.POINTER(C.c_double)))
+
+
+@pytest.mark.parametrize("case", ["pingpong"])
+def test_ab_ticks_forced_on_small_batches_match_oracle(case):
+    env = dict(os.environ, TE_PINGPONG_MIN_MB="0", PYTHONPATH=os.pathsep.join([os.path.dirname(__file__), os.path.dirname(os.path.dirname(__file__))]))
+    p = subprocess.run([sys.executable, "-c", "import test_gpu_mixed_configs as t; t._pingpong_small_case()"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "pingpong small case ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
+def test_ab_ticks_equal_in_place_ticks_bit_for_bit():
+    """The same 4 * 10^6-target batch stepped in place (policy off) and A -> B (policy on, the default at this size): the
+    records must be the same bits.  Two child processes (the thresholds are read once per process), 20 000-target sample."""
+    code = ("import numpy as np, torch, target_estimation_amd as te\n"
+            "from target_estimation_amd.streams import make_stream\n"
+            "import os, sys\n"
+            "sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+            "from conftest import model_path\n"
+            "N, T, dt = 4_000_000, 5, 0.004\n"
+            "st = make_stream(1, N, T, dt, 11)\n"
+            "mgr = te.TargetManager(model_path('angular_velocities'))\n"
+            "ids = np.arange(N, dtype=np.uint32)\n"
+            "mgr.init_batch(ids, dt, 0.0, st['p0'].cpu().numpy())\n"
+            "b = mgr.batches()[0]\n"
+            "b.step_sequence(dt, st['meas'], None, use_graph=False)\n"
+            "b.step(dt, st['meas'][0])\n"
+            "x, P = mgr.get_state_batch(ids[::200])\n"
+            "np.save(sys.argv[1], np.concatenate([x.ravel(), P.ravel()]))\n" % os.path.dirname(os.path.dirname(__file__)))
+    import tempfile
+    out = []
+    for mb in ("-1", "1024"):
+        f = tempfile.NamedTemporaryFile(suffix=".npy", delete=False).name
+        env = dict(os.environ, TE_PINGPONG_MIN_MB=mb)
+        p = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        out.append(np.load(f))
+        os.unlink(f)
+    assert np.isfinite(out[0]).all()
+    np.testing.assert_array_equal(out[0], out[1])
