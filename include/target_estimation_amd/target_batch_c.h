@@ -56,11 +56,37 @@ target_manager_c* target_manager_new_ex(const char* file, int dtype, int lanes_p
 /* all launches of this manager go to `hip_stream` (a hipStream_t; NULL = default stream) */
 int target_manager_set_stream(target_manager_c* self, void* hip_stream);
 int target_manager_synchronize(target_manager_c* self);
-/* rt_logger-equivalent snapshots: with a directory set (here or by env TARGET_ESTIMATION_LOG_DIR) every
- * target_manager_log() appends one row per target to <dir>/time_<id>, est_pose_<id>, est_twist_<id>,
- * est_acc_<id>, cov_diag_<id> (text format of the reference's writeTxtFile, utils.hpp:96-120).  NULL or
- * "" switches it off (log() is then a no-op, as the reference without LOGGER_ON). */
+/* rt_logger-equivalent snapshots (the reference publishes measurement / pose / twist / acceleration / covariance per
+ * target, src/target_interface.cpp:32-40): with a directory set (here or by env TARGET_ESTIMATION_LOG_DIR) every
+ * target_manager_log() appends one row per selected target to <dir>/time_<id>, meas_pose_<id>, est_pose_<id>,
+ * est_twist_<id> (the files of the reference's test and plot script, test/target_manager_test.cpp:164-168,
+ * matlab/plot_target_manager_test.m:9-13) and pose_<id> ([xyz rpy]), est_acc_<id>, covariance_<id> (P, row-major), in
+ * the text format of the reference's writeTxtFile (utils.hpp:96-120).  Selected = target_manager_set_log_targets, or
+ * every target while there are at most 64; otherwise one <channel>_all file per channel with the id in front of every
+ * row.  Files stay open between calls; one buffered write per file per call.  NULL or "" switches logging off (log()
+ * is then a no-op, as the reference without LOGGER_ON).  A directory switches the measured-pose rows on. */
 int target_manager_set_log_directory(target_manager_c* self, const char* dir);
+int target_manager_set_log_targets(target_manager_c* self, const unsigned int* ids, long n);   /* n == 0: automatic */
+/* TargetInterface::getMeasuredPose (include/target_estimation/target_interface.hpp:130, src/target_interface.cpp:117-121,
+ * :142-146): the last measurement of a target, [0 0 0 0 0 0 1] before the first.  The filters never read it back, so it is
+ * kept only on request: one row of 7 doubles per target beside the records, written by a small kernel behind every
+ * step (56 B per measured target per tick; off by default).  The getter returns false for an unknown id or when the
+ * rows are not kept.  Linear models fed through target_batch_step_host (x y z only) report the identity orientation. */
+int target_manager_set_keep_measurement(target_manager_c* self, int on);
+bool target_manager_get_measured_pose(target_manager_c* self, unsigned int id, double* pose7);
+/* TargetInterface::getPeriodEstimate (target_interface.hpp:94, src/target_interface.cpp:80-87): 2 pi / |omega| of the
+ * current twist, -1 if the target is not rotating */
+bool target_manager_get_period_estimate(target_manager_c* self, unsigned int id, double* period);
+/* TargetInterface::getEstimatedTransform (target_interface.hpp:106, src/target_interface.cpp:95-98): the isometry T_ as
+ * a row-major 4x4 matrix [R t; 0 0 0 1] */
+bool target_manager_get_estimated_transform(target_manager_c* self, unsigned int id, double* T16);
+/* TargetInterface::getN / getM (target_interface.hpp:142,148); 0 for an unknown id */
+int target_manager_get_n(target_manager_c* self, unsigned int id);
+int target_manager_get_m(target_manager_c* self, unsigned int id);
+/* getTarget(id)->getEstimator()->getQ() / getR() / getP0() (include/target_estimation/kalman.hpp:74,79,89): the matrices
+ * the target was created with, row-major doubles (Q, P0: n*n; R: m*m); any pointer may be NULL.  false: unknown id, or
+ * (P0 only) the manager saw more than 4096 distinct P0 matrices for this model and stopped mirroring them. */
+bool target_manager_get_model_matrices(target_manager_c* self, unsigned int id, double* Q, double* R, double* P0);
 const char* target_manager_last_error(void);
 
 /* TargetManager::init(type,id,dt0,t0,Q,R,P0,p0,v0,a0), target_manager.hpp:85-87.
@@ -125,7 +151,8 @@ double target_manager_get_intersection_time_with_sphere(target_manager_c* self, 
                                                          const double* origin, double radius);
 /* Pose at t1 + delta ([0 0 0 0 0 0 1] if none); returns whether an intersection exists.  Replaces
  * IntersectionSolver::getIntersectionPoseWithSphere, intersection_solver.cpp:91-104, WITHOUT its
- * moving-average convergence gate (:105-120; SURVEY 8f "next").  delta may be NULL. */
+ * moving-average convergence gate (:105-120; the gated form is target_manager_intersect_sphere_converged_batch below).
+ * delta may be NULL. */
 bool target_manager_get_intersection_pose_with_sphere(target_manager_c* self, unsigned int id, double t1,
                                                       const double* origin, double radius, double* pose,
                                                       double* delta);
@@ -145,6 +172,22 @@ long target_manager_intersect_sphere_converged_batch(target_manager_c* self, con
                                                      double pos_th, double ang_th, const double* origin, double radius,
                                                      int filters_length, double* delta, double* pose,
                                                      unsigned char* converged, unsigned char* found, double* filtered_errors);
+
+/* The reference's IntersectionSolver as an OBJECT (include/target_estimation/intersection_solver.hpp:56-126): a manager
+ * handle plus ONE convergence gate -- two moving averages of window filters_length (default 250, :63) and the previous
+ * intersection pose -- shared by every id queried through it, as the reference's members are (src/intersection_solver.cpp:
+ * 19-40).  ..._get_time_with_sphere = getIntersectionTimeWithSphere (:73, .cpp:42-89); ..._get_pose_with_sphere =
+ * getIntersectionPoseWithSphere (:86, .cpp:91-124): pose7 = the pose at t1 + delta, [0 0 0 0 0 0 1] if there is no
+ * intersection; returns whether both filtered errors are within their thresholds.  The solver does not own the manager,
+ * which must outlive it.  ..._last_errors: the filtered errors of the last call that found an intersection. */
+typedef void target_intersection_solver_c;
+target_intersection_solver_c* target_intersection_solver_new(target_manager_c* manager, unsigned int filters_length);
+void target_intersection_solver_delete(target_intersection_solver_c* solver);
+double target_intersection_solver_get_time_with_sphere(target_intersection_solver_c* solver, unsigned int id, double t1,
+                                                        const double* origin, double radius);
+bool target_intersection_solver_get_pose_with_sphere(target_intersection_solver_c* solver, unsigned int id, double t1, double pos_th,
+                                                     double ang_th, const double* origin, double radius, double* pose7);
+void target_intersection_solver_last_errors(target_intersection_solver_c* solver, double* pos_error_filtered, double* ang_error_filtered);
 
 /* ---- device-resident dense path ---------------------------------------------------------- */
 int target_manager_num_batches(target_manager_c* self);

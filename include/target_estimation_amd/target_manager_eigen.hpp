@@ -47,8 +47,21 @@ class EstimatorView {
   EstimatorView(target_manager_c* m, unsigned id) : m_(m), id_(id) {}
   Eigen::VectorXd getState() const { Eigen::VectorXd x; Eigen::MatrixXd P; fetch(x, P); return x; }
   Eigen::MatrixXd getP() const { Eigen::VectorXd x; Eigen::MatrixXd P; fetch(x, P); return P; }
+  Eigen::MatrixXd getQ() const { return model(0); }    // kalman.hpp:74
+  Eigen::MatrixXd getR() const { return model(1); }    // kalman.hpp:79
+  Eigen::MatrixXd getP0() const { return model(2); }   // kalman.hpp:89
 
  private:
+  Eigen::MatrixXd model(int which) const {   // 0 Q, 1 R, 2 P0: the matrices the target was created with
+    const int n = target_manager_get_n(m_, id_), m = target_manager_get_m(m_, id_);
+    Eigen::MatrixXd out;
+    if (n <= 0) return out;
+    double Q[18 * 18], R[6 * 6], P0[18 * 18];
+    if (!target_manager_get_model_matrices(m_, id_, which == 0 ? Q : nullptr, which == 1 ? R : nullptr, which == 2 ? P0 : nullptr)) return out;
+    if (which == 1) out = Eigen::Map<RowMatrixXd>(R, m, m);
+    else out = Eigen::Map<RowMatrixXd>(which == 0 ? Q : P0, n, n);
+    return out;
+  }
   void fetch(Eigen::VectorXd& x, Eigen::MatrixXd& P) const {
     double xb[18], Pb[18 * 18];
     const long n = target_manager_get_state_batch(m_, &id_, 1, xb, Pb);
@@ -73,6 +86,26 @@ class TargetHandle {
   Eigen::Vector6d getEstimatedTwist(const double& t) const { Eigen::Vector6d v; at(t, nullptr, v.data(), nullptr); return v; }
   Eigen::Vector6d getEstimatedAcceleration(const double& t) const { Eigen::Vector6d a; at(t, nullptr, nullptr, a.data()); return a; }
   double getTime() const { double t = 0; target_manager_get_time(m_, id_, &t); return t; }
+  // target_interface.hpp:94: 2 pi / |omega|, -1 if the target is not rotating
+  double getPeriodEstimate() const { double p = -1.0; target_manager_get_period_estimate(m_, id_, &p); return p; }
+  // target_interface.hpp:106
+  Eigen::Isometry3d getEstimatedTransform() const {
+    double T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    target_manager_get_estimated_transform(m_, id_, T);
+    Eigen::Isometry3d out;
+    out.matrix() = Eigen::Map<Eigen::Matrix<double, 4, 4, Eigen::RowMajor> >(T, 4, 4);
+    return out;
+  }
+  // target_interface.hpp:130: the last measurement ([0 0 0 0 0 0 1] before the first).  The manager keeps it only on
+  // request (target_manager_set_keep_measurement / TargetManager::setKeepMeasurement below).
+  Eigen::Vector7d getMeasuredPose() const {
+    Eigen::Vector7d p = Eigen::Vector7d::Zero();
+    p(6) = 1.0;
+    target_manager_get_measured_pose(m_, id_, p.data());
+    return p;
+  }
+  unsigned int getN() const { return (unsigned int)target_manager_get_n(m_, id_); }   // target_interface.hpp:142
+  unsigned int getM() const { return (unsigned int)target_manager_get_m(m_, id_); }   // :148
   long long getNumberMeasurements() const { return target_manager_get_n_measurements(m_, id_); }
   const EstimatorView* getEstimator() const { return &est_; }
 
@@ -144,10 +177,39 @@ class TargetManager {
   double getIntersectionTimeWithSphere(const unsigned int& id, const double& t1, const Eigen::Vector3d& origin, const double& radius) {
     return target_manager_get_intersection_time_with_sphere(m_, id, t1, origin.data(), radius);
   }
+  void setKeepMeasurement(bool on) { target_manager_set_keep_measurement(m_, on ? 1 : 0); }   // see TargetHandle::getMeasuredPose
   target_manager_c* handle() { return m_; }
 
  protected:
   target_manager_c* m_;
+};
+
+// The reference's IntersectionSolver (include/target_estimation/intersection_solver.hpp:56-126): same constructor, same two
+// methods with the same Eigen argument types, ONE convergence gate per solver object (src/intersection_solver.cpp:19-40,
+// 91-124) -- over the C entry points target_intersection_solver_*.
+class IntersectionSolver {
+ public:
+  typedef std::shared_ptr<IntersectionSolver> Ptr;
+  IntersectionSolver(TargetManager::Ptr target_manager, const unsigned int filters_length = 250)   // :63
+      : target_manager_(target_manager), s_(target_intersection_solver_new(target_manager ? target_manager->handle() : nullptr, filters_length)) {
+    if (!s_) throw "IntersectionSolver constructor failed!";
+  }
+  ~IntersectionSolver() { target_intersection_solver_delete(s_); }
+  IntersectionSolver(const IntersectionSolver&) = delete;
+  IntersectionSolver& operator=(const IntersectionSolver&) = delete;
+  // :73
+  double getIntersectionTimeWithSphere(const unsigned int& id, const double& t1, const Eigen::Vector3d& origin, const double& radius) {
+    return target_intersection_solver_get_time_with_sphere(s_, id, t1, origin.data(), radius);
+  }
+  // :86
+  bool getIntersectionPoseWithSphere(const unsigned int& id, const double& t1, const double& pos_th, const double& ang_th,
+                                     const Eigen::Vector3d& origin, const double& radius, Eigen::Vector7d& intersection_pose) {
+    return target_intersection_solver_get_pose_with_sphere(s_, id, t1, pos_th, ang_th, origin.data(), radius, intersection_pose.data());
+  }
+
+ private:
+  TargetManager::Ptr target_manager_;   // keeps the manager alive, as the reference's member does
+  target_intersection_solver_c* s_;
 };
 
 }  // namespace target_estimation_amd

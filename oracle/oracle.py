@@ -43,8 +43,11 @@ def load(fast=False):
         g("orc_target_add_measurement").argtypes = [C.c_void_p, C.c_double, dp]
         g("orc_target_update").argtypes = [C.c_void_p, C.c_double]
         g("orc_target_get_state").argtypes = [C.c_void_p, dp, dp]
-        for nm in ("orc_target_get_pose", "orc_target_get_twist", "orc_target_get_acceleration"):
+        for nm in ("orc_target_get_pose", "orc_target_get_twist", "orc_target_get_acceleration", "orc_target_get_measured_pose",
+                   "orc_target_get_pose6", "orc_target_get_transform"):
             g(nm).argtypes = [C.c_void_p, dp]
+        g("orc_target_get_period_estimate").restype = C.c_double
+        g("orc_target_get_period_estimate").argtypes = [C.c_void_p]
         for nm in ("orc_target_get_pose_at", "orc_target_get_twist_at",
                    "orc_target_get_acceleration_at"):
             g(nm).argtypes = [C.c_void_p, C.c_double, dp]
@@ -182,6 +185,19 @@ class OracleBatch:
 
     def acceleration(self):
         return self._get("orc_target_get_acceleration", 6)
+
+    def measured_pose(self):
+        return self._get("orc_target_get_measured_pose", 7)
+
+    def pose6(self):
+        return self._get("orc_target_get_pose6", 6)
+
+    def transform(self):
+        return self._get("orc_target_get_transform", 16).reshape(self.N, 4, 4)
+
+    def period_estimate(self):
+        f = self._f("orc_target_get_period_estimate")
+        return np.array([f(self._at(i)) for i in range(self.N)])
 
     def pose_at(self, t1):
         return self._get("orc_target_get_pose_at", 7, float(t1))

@@ -70,6 +70,10 @@ enum {
   void orc_target_get_pose_##SFX(const orc_target_##SFX* tg, double* pose7);                      \
   void orc_target_get_twist_##SFX(const orc_target_##SFX* tg, double* twist6);                    \
   void orc_target_get_acceleration_##SFX(const orc_target_##SFX* tg, double* acc6);               \
+  void orc_target_get_measured_pose_##SFX(const orc_target_##SFX* tg, double* pose7);             \
+  void orc_target_get_pose6_##SFX(const orc_target_##SFX* tg, double* pose6);                     \
+  void orc_target_get_transform_##SFX(const orc_target_##SFX* tg, double* T16);                   \
+  double orc_target_get_period_estimate_##SFX(const orc_target_##SFX* tg);                        \
   void orc_target_get_pose_at_##SFX(const orc_target_##SFX* tg, double t1, double* pose7);        \
   void orc_target_get_twist_at_##SFX(const orc_target_##SFX* tg, double t1, double* twist6);      \
   void orc_target_get_acceleration_at_##SFX(const orc_target_##SFX* tg, double t1, double* a6);   \

@@ -522,6 +522,33 @@ void FN(orc_target_get_acceleration)(const TGT* tg, double* acc6) {
   for (int i = 0; i < 6; ++i) acc6[i] = (double)tg->acceleration[i];
 }
 
+/* TargetInterface::getMeasuredPose target_interface.cpp:117-121 (measured_pose_: initPose, then the last measurement :142-146) */
+void FN(orc_target_get_measured_pose)(const TGT* tg, double* pose7) {
+  for (int i = 0; i < 7; ++i) pose7[i] = (double)tg->measured_pose[i];
+}
+
+/* pose_internal_ = [xyz rpy] (isometryToPose6d, geometry.hpp:602-608): the rt_logger "pose" channel, target_interface.cpp:36 */
+void FN(orc_target_get_pose6)(const TGT* tg, double* pose6) {
+  for (int i = 0; i < 6; ++i) pose6[i] = (double)tg->pose_internal[i];
+}
+
+/* TargetInterface::getEstimatedTransform target_interface.cpp:95-98: T_ as a row-major 4x4 */
+void FN(orc_target_get_transform)(const TGT* tg, double* T16) {
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) T16[r * 4 + c] = (double)tg->T_lin[r * 3 + c];
+    T16[r * 4 + 3] = (double)tg->T_trans[r];
+  }
+  T16[12] = 0; T16[13] = 0; T16[14] = 0; T16[15] = 1;
+}
+
+/* TargetInterface::getPeriodEstimate target_interface.cpp:80-87 */
+double FN(orc_target_get_period_estimate)(const TGT* tg) {
+  const double wx = (double)tg->twist[3], wy = (double)tg->twist[4], wz = (double)tg->twist[5];
+  const double omega_norm = sqrt(wx * wx + wy * wy + wz * wz);
+  if (omega_norm > 0) return 2 * M_PI / omega_norm;
+  return -1.0;
+}
+
 /* getEstimatedPose(t1): uniform_velocity.cpp:117-127, uniform_acceleration.cpp:120-130,
  * angular_rates.cpp:140-151, angular_velocities.cpp:171-184 */
 void FN(orc_target_get_pose_at)(const TGT* tg, double t1, double* pose7) {

@@ -45,6 +45,20 @@ SIGNATURES = {
     "target_manager_synchronize": (C.c_int, [C.c_void_p]),
     "target_manager_set_log_directory": (C.c_int, [C.c_void_p, C.c_char_p]),
     "target_manager_last_error": (C.c_char_p, []),
+    "target_intersection_solver_new": (C.c_void_p, [C.c_void_p, C.c_uint]),
+    "target_intersection_solver_delete": (None, [C.c_void_p]),
+    "target_intersection_solver_get_time_with_sphere": (C.c_double, [C.c_void_p, C.c_uint, C.c_double, c_double_p, C.c_double]),
+    "target_intersection_solver_get_pose_with_sphere": (C.c_bool, [C.c_void_p, C.c_uint, C.c_double, C.c_double, C.c_double, c_double_p,
+                                                                   C.c_double, c_double_p]),
+    "target_intersection_solver_last_errors": (None, [C.c_void_p, c_double_p, c_double_p]),
+    "target_manager_set_log_targets": (C.c_int, [C.c_void_p, c_uint_p, C.c_long]),
+    "target_manager_set_keep_measurement": (C.c_int, [C.c_void_p, C.c_int]),
+    "target_manager_get_measured_pose": (C.c_bool, [C.c_void_p, C.c_uint, c_double_p]),
+    "target_manager_get_period_estimate": (C.c_bool, [C.c_void_p, C.c_uint, c_double_p]),
+    "target_manager_get_estimated_transform": (C.c_bool, [C.c_void_p, C.c_uint, c_double_p]),
+    "target_manager_get_n": (C.c_int, [C.c_void_p, C.c_uint]),
+    "target_manager_get_m": (C.c_int, [C.c_void_p, C.c_uint]),
+    "target_manager_get_model_matrices": (C.c_bool, [C.c_void_p, C.c_uint, c_double_p, c_double_p, c_double_p]),
     "target_manager_init_typed": (C.c_int, [C.c_void_p, C.c_int, C.c_uint, C.c_double, C.c_double, c_double_p,
                                             c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     "target_manager_init_batch": (C.c_long, [C.c_void_p, c_uint_p, C.c_long, C.c_double, C.c_double, c_double_p,

@@ -1,5 +1,6 @@
 // batch_store.cpp -- see batch_store.hpp.
 #include "batch_store.hpp"
+#include "measured_pose.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -73,8 +74,90 @@ int Batch::add_class(const double* Q, const double* R) {
     for (int c = 0; c < m; ++c) put(qr_r_word(type_, sep, r, c), R[r * m + c]);
   TE_HIP_CHECK(hipMemcpy(static_cast<char*>(d_qr_) + (size_t)n_classes_ * words * es, host.data(), host.size(), hipMemcpyHostToDevice));
   class_index_.emplace(class_key(Q, n * n, R, m * m), n_classes_);
+  class_qr_.emplace_back((size_t)(n * n + m * m));
+  std::copy(Q, Q + n * n, class_qr_.back().begin());
+  std::copy(R, R + m * m, class_qr_.back().begin() + n * n);
   if (n_classes_ == 1) drop_graphs();   // the single-class kernels were recorded: from now on the per-class ones run
   return n_classes_++;
+}
+
+void Batch::launch_step(const StepParams& p, hipStream_t st, int meas_rows) {
+  ops_->step(p, st);
+  if (!keep_meas_ || !p.meas || p.n <= 0) return;
+  const unsigned blocks = (unsigned)((p.n + 255) / 256);
+  if (dtype_ == F64)
+    keep_measurement_kernel<double><<<blocks, 256, 0, st>>>(static_cast<const double*>(p.meas), p.meas_ld, p.tick_stride, p.has_meas, p.has_stride,
+                                                            p.n_ticks, p.idx, p.n, meas_rows, d_lastmeas_);
+  else
+    keep_measurement_kernel<float><<<blocks, 256, 0, st>>>(static_cast<const float*>(p.meas), p.meas_ld, p.tick_stride, p.has_meas, p.has_stride,
+                                                           p.n_ticks, p.idx, p.n, meas_rows, d_lastmeas_);
+}
+
+void Batch::set_keep_measurement(bool on) {
+  if (on == keep_meas_) return;
+  touch();
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));
+  drop_graphs();   // recorded sequences do (not) contain the row kernels
+  if (on) {
+    if (cap_ > 0) {
+      TE_HIP_CHECK(hipMalloc((void**)&d_lastmeas_, sizeof(double) * 7 * (size_t)cap_));
+      init_measured_rows_kernel<<<(unsigned)((cap_ * 7 + 255) / 256), 256, 0, stream_>>>(d_lastmeas_, 0, cap_);
+      TE_HIP_CHECK(hipGetLastError());
+    }
+  } else {
+    (void)hipFree(d_lastmeas_);
+    d_lastmeas_ = nullptr;
+  }
+  keep_meas_ = on;
+}
+
+void Batch::measured_poses(const int* slots, long n, double* out) {
+  if (!keep_meas_) throw std::runtime_error("target_estimation_amd: measured poses are not kept (target_manager_set_keep_measurement)");
+  flush();
+  if (n <= 0) return;
+  if (!slots) {
+    TE_HIP_CHECK(hipMemcpyAsync(out, d_lastmeas_, sizeof(double) * 7 * (size_t)n, hipMemcpyDeviceToHost, stream_));
+  } else {
+    for (long i = 0; i < n; ++i)
+      TE_HIP_CHECK(hipMemcpyAsync(out + 7 * i, d_lastmeas_ + 7 * (long)slots[i], sizeof(double) * 7, hipMemcpyDeviceToHost, stream_));
+  }
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Batch::class_matrices(long slot, double* Q, double* R) {
+  const int n = ops_->L.n, m = ops_->L.m;
+  int cls = 0;
+  if (n_classes_ > 1) {
+    flush();
+    TE_HIP_CHECK(hipMemcpyAsync(&cls, d_cls_ + slot, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    TE_HIP_CHECK(hipStreamSynchronize(stream_));
+  }
+  const std::vector<double>& qr = class_qr_.at((size_t)cls);
+  if (Q) std::copy(qr.begin(), qr.begin() + n * n, Q);
+  if (R) std::copy(qr.begin() + n * n, qr.begin() + n * n + m * m, R);
+}
+
+int Batch::intern_p0(const double* P0) {
+  if (!p0_kept_) return -1;
+  const int n = ops_->L.n;
+  std::string key(reinterpret_cast<const char*>(P0), sizeof(double) * (size_t)n * n);
+  auto it = p0_index_.find(key);
+  if (it != p0_index_.end()) return it->second;
+  if (p0_tab_.size() >= kP0TableMax) {   // too many distinct initial covariances to mirror on the host: stop keeping them
+    p0_kept_ = false;
+    p0_tab_.clear(); p0_index_.clear(); slot_p0_.clear();
+    return -1;
+  }
+  p0_tab_.emplace_back(P0, P0 + (size_t)n * n);
+  p0_index_.emplace(std::move(key), (int)p0_tab_.size() - 1);
+  return (int)p0_tab_.size() - 1;
+}
+
+bool Batch::initial_covariance(long slot, double* P0) {
+  if (!p0_kept_ || slot < 0 || (size_t)slot >= slot_p0_.size()) return false;
+  const std::vector<double>& v = p0_tab_[(size_t)slot_p0_[(size_t)slot]];
+  std::copy(v.begin(), v.end(), P0);
+  return true;
 }
 
 StepParams Batch::base_params() const {
@@ -92,7 +175,7 @@ Batch::~Batch() {
   (void)hipFree(d_qr_); (void)hipFree(d_rec_); (void)hipFree(d_rec_alt_); (void)hipFree(d_tbase_); (void)hipFree(d_nmbase_); (void)hipFree(d_cls_);
   (void)hipFree(d_idx_); (void)hipFree(d_aos_); (void)hipFree(d_meas_); (void)hipFree(d_mask_); (void)hipFree(d_P0_);
   (void)hipFree(d_gate_ring_); (void)hipFree(d_gate_sum_); (void)hipFree(d_gate_state_); (void)hipFree(d_gate_prev_);
-  (void)hipFree(d_dtper_);
+  (void)hipFree(d_dtper_); (void)hipFree(d_lastmeas_);
   if (h_pin_) (void)hipHostFree(h_pin_);
   if (h_cache_) (void)hipHostFree(h_cache_);
   if (h_done_) (void)hipHostFree(h_done_);
@@ -168,6 +251,13 @@ void Batch::reserve(long n) {
   TE_HIP_CHECK(hipStreamSynchronize(stream_));
   (void)hipFree(d_rec_); (void)hipFree(d_tbase_); (void)hipFree(d_nmbase_); (void)hipFree(d_cls_);
   (void)hipFree(d_rec_alt_); d_rec_alt_ = nullptr;   // re-created at the new capacity by the next A -> B tick
+  if (keep_meas_) {
+    double* lm = nullptr;
+    TE_HIP_CHECK(hipMalloc((void**)&lm, sizeof(double) * 7 * (size_t)want));
+    if (d_lastmeas_ && cap_ > 0) TE_HIP_CHECK(hipMemcpy(lm, d_lastmeas_, sizeof(double) * 7 * (size_t)cap_, hipMemcpyDeviceToDevice));
+    (void)hipFree(d_lastmeas_);
+    d_lastmeas_ = lm;
+  }
   d_rec_ = rec; d_tbase_ = tb; d_nmbase_ = nm; d_cls_ = cl; cap_ = want;
   drop_graphs();
 }
@@ -228,6 +318,23 @@ long Batch::append(long count, const unsigned* ids, double t0, const double* P0,
   ops_->init(a, stream_);
   TE_HIP_CHECK(hipGetLastError());
   if (d_gate_ring_) { if (gate_cap_ < cap_) gate_reserve(gate_window_); gate_reset(first, count); }
+  if (keep_meas_) {
+    init_measured_rows_kernel<<<(unsigned)((count * 7 + 255) / 256), 256, 0, stream_>>>(d_lastmeas_, first, count);
+    TE_HIP_CHECK(hipGetLastError());
+  }
+  if (p0_kept_) {   // host mirror of the initial covariances (initial_covariance)
+    slot_p0_.resize((size_t)first, 0);
+    if (P0_index) {
+      std::vector<int> row((size_t)P0_count);
+      for (long k = 0; k < P0_count && p0_kept_; ++k) row[(size_t)k] = intern_p0(P0 + (size_t)k * N * N);
+      for (long i = 0; i < count && p0_kept_; ++i) slot_p0_.push_back(row[(size_t)P0_index[i]]);
+    } else if (per_target_P0) {
+      for (long i = 0; i < count && p0_kept_; ++i) { const int r = intern_p0(P0 + (size_t)i * N * N); if (p0_kept_) slot_p0_.push_back(r); }
+    } else {
+      const int r = intern_p0(P0);
+      if (p0_kept_) slot_p0_.insert(slot_p0_.end(), (size_t)count, r);
+    }
+  }
   TE_HIP_CHECK(hipStreamSynchronize(stream_));  // host staging arrays may be pageable
   slot_ids_.insert(slot_ids_.end(), ids, ids + count);
   n_ += count;
@@ -242,9 +349,12 @@ unsigned Batch::erase_slot(long slot) {
     ops_->move_record(d_rec_, last, slot, d_tbase_, d_nmbase_, d_cls_, stream_);
     TE_HIP_CHECK(hipGetLastError());
     gate_move(last, slot);
+    if (d_lastmeas_) TE_HIP_CHECK(hipMemcpyAsync(d_lastmeas_ + 7 * slot, d_lastmeas_ + 7 * last, sizeof(double) * 7, hipMemcpyDeviceToDevice, stream_));
+    if (p0_kept_) slot_p0_[(size_t)slot] = slot_p0_[(size_t)last];
     moved = slot_ids_[(size_t)last];
     slot_ids_[(size_t)slot] = moved;
   }
+  if (p0_kept_) slot_p0_.pop_back();
   slot_ids_.pop_back();
   n_ = last;
   return moved;
@@ -278,6 +388,8 @@ void Batch::erase_slots(const int* slots, long k, std::vector<std::pair<unsigned
     TE_HIP_CHECK(hipGetLastError());
     for (long j = 0; j < m; ++j) {
       gate_move(src[(size_t)j], dst[(size_t)j]);
+      if (d_lastmeas_) TE_HIP_CHECK(hipMemcpyAsync(d_lastmeas_ + 7 * (long)dst[(size_t)j], d_lastmeas_ + 7 * (long)src[(size_t)j], sizeof(double) * 7, hipMemcpyDeviceToDevice, stream_));
+      if (p0_kept_) slot_p0_[(size_t)dst[(size_t)j]] = slot_p0_[(size_t)src[(size_t)j]];
       const unsigned id = slot_ids_[(size_t)src[(size_t)j]];
       slot_ids_[(size_t)dst[(size_t)j]] = id;
       moves_out.emplace_back(id, dst[(size_t)j]);
@@ -285,6 +397,7 @@ void Batch::erase_slots(const int* slots, long k, std::vector<std::pair<unsigned
     TE_HIP_CHECK(hipStreamSynchronize(stream_));   // src / dst go out of scope
   }
   slot_ids_.resize((size_t)new_n);
+  if (p0_kept_) slot_p0_.resize((size_t)new_n);
   n_ = new_n;
 }
 
@@ -296,7 +409,7 @@ void Batch::step_dense(double dt, const void* meas_dev, long ld, const unsigned 
   p.reverse = (flip_ && zigzag()) ? 1 : 0;   // zig-zag: consecutive dense ticks walk the tiles in opposite directions
   flip_ = !flip_;
   if (pingpong()) p.rec_out = alt_records();
-  ops_->step(p, stream_);
+  launch_step(p, stream_, host_meas_rows_);
   if (p.rec_out) std::swap(d_rec_, d_rec_alt_);   // later launches on the stream see the finished tick in the new current buffer
   t_acc_ += dt;
   if (meas_dev && !has_dev) nm_acc_ += 1;
@@ -327,7 +440,7 @@ void Batch::step_sequence(long n_ticks, double dt, const void* meas_base, long t
     for (long s = 0; s < n_ticks; ++s) {
       StepParams p = params(s);
       if (ab) p.rec_out = alt_records();
-      ops_->step(p, stream_);
+      launch_step(p, stream_);
       if (ab) std::swap(d_rec_, d_rec_alt_);
     }
     TE_HIP_CHECK(hipGetLastError());
@@ -352,9 +465,11 @@ void Batch::step_sequence(long n_ticks, double dt, const void* meas_base, long t
       TE_HIP_CHECK(hipStreamBeginCapture(cap_stream_, hipStreamCaptureModeThreadLocal));
       try {
         for (long s = 0; s < n_ticks; ++s) {
-          ops_->step(params(s), cap_stream_);
+          launch_step(params(s), cap_stream_);
+#ifdef TE_TEST_HOOKS   // only in libtarget_estimation_amd_testhooks.so (csrc/Makefile `testhooks`)
           if (s == 0 && std::getenv("TE_TEST_FAIL_IN_CAPTURE"))   // test hook: a launch that throws between Begin and EndCapture
             throw std::runtime_error("target_estimation_amd: injected failure inside stream capture");
+#endif
         }
         TE_HIP_CHECK(hipGetLastError());
       } catch (...) {
@@ -397,7 +512,7 @@ void Batch::enqueue_tick(hipStream_t st, long s, double dt, const SeqSpec& q, bo
     p.q_radius = radius; p.q_delta = q.delta_dev; p.q_pose = q.pose_dev;
   }
   if (ab) p.rec_out = alt_records();
-  ops_->step(p, st);
+  launch_step(p, st);
   if (ab) std::swap(d_rec_, d_rec_alt_);
   if (query && !fused_q) {
     IntersectArgs a;
@@ -420,7 +535,7 @@ void Batch::step_fused(long n_ticks, double dt, const void* meas_base, long tick
   StepParams p = base_params();
   p.meas = meas_base; p.meas_ld = ld; p.has_meas = has_base; p.dt = dt;
   p.n_ticks = (int)n_ticks; p.tick_stride = tick_stride; p.has_stride = has_stride;
-  ops_->step(p, stream_);
+  launch_step(p, stream_);
   TE_HIP_CHECK(hipGetLastError());
   t_acc_ += dt * (double)n_ticks;
   if (meas_base && !has_base) nm_acc_ += n_ticks;
@@ -439,7 +554,7 @@ void Batch::step_indexed(const int* slots, long n, double dt, const double* meas
   StepParams p = base_params();
   p.n = n; p.idx = d_idx_; p.meas = meas_aos ? d_meas_ : nullptr; p.meas_ld = n;
   p.has_meas = (meas_aos && has) ? d_mask_ : nullptr; p.dt = dt;
-  ops_->step(p, stream_);
+  launch_step(p, stream_);
   TE_HIP_CHECK(hipGetLastError());
   TE_HIP_CHECK(hipStreamSynchronize(stream_));  // caller's host arrays may be reused after return
 }
@@ -450,7 +565,7 @@ void Batch::step_indexed_dev(const int* idx_dev, long n, double dt, const void* 
   StepParams p = base_params();
   p.n = n; p.idx = idx_dev; p.meas = meas_soa_dev; p.meas_ld = ld;
   p.has_meas = meas_soa_dev ? has_dev : nullptr; p.dt = dt;
-  ops_->step(p, stream_);
+  launch_step(p, stream_);
   TE_HIP_CHECK(hipGetLastError());
 }
 
@@ -491,7 +606,9 @@ void Batch::step_dense_host_soa(double dt, const void* meas_soa, long ld_host, c
                                   angular ? 7 : 3, hipMemcpyHostToDevice, stream_));
   }
   if (has) TE_HIP_CHECK(hipMemcpyAsync(d_mask_, has, (size_t)n_, hipMemcpyHostToDevice, stream_));
+  host_meas_rows_ = (type_ == ANGULAR_RATES || type_ == ANGULAR_VELOCITIES) ? 7 : 3;   // what was transported (measured_pose.hpp)
   step_dense(dt, meas_soa ? d_meas_ : nullptr, stage_cap_, (meas_soa && has) ? d_mask_ : nullptr);
+  host_meas_rows_ = 7;
   TE_HIP_CHECK(hipGetLastError());
   TE_HIP_CHECK(hipStreamSynchronize(stream_));  // caller's host arrays may be reused after return
 }
@@ -583,7 +700,7 @@ void Batch::flush() {
     p.o_pose = d_cache_; p.o_twist = d_cache_ + 7 * n_; p.o_acc = d_cache_ + 13 * n_;
     p.done_flag = d_done_; p.done_seq = seq;
   }
-  ops_->step(p, stream_);
+  launch_step(p, stream_);
   if (cache_valid_ && !fused) {   // keep the getter table current: only the stepped slots change
     OutArgs a;
     a.rec = d_rec_; a.idx = p.idx; a.n = k; a.by_slot = 1;

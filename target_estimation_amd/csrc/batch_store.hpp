@@ -142,6 +142,15 @@ class Batch {
   DevIdentity dev_identity() const { return DevIdentity{d_rec_, d_qr_, d_tbase_, d_nmbase_, n_}; }
   void prepare() { touch(); }
 
+  // TargetInterface::getMeasuredPose (target_interface.cpp:117-121), optional: see measured_pose.hpp
+  void set_keep_measurement(bool on);
+  bool keep_measurement() const { return keep_meas_; }
+  void measured_poses(const int* slots, long n, double* pose7_rows);   // host rows [n][7]; slots == null: all
+  // KalmanFilterInterface::getQ / getR / getP0 of one target (kalman.hpp:74-89): the matrices it was created with, as
+  // given (doubles, row-major).  P0 is kept on the host as a table of the distinct matrices seen (up to kP0TableMax;
+  // beyond that initial_covariance() returns false).
+  void class_matrices(long slot, double* Q, double* R);
+  bool initial_covariance(long slot, double* P0);
   void get_state(const int* slots, long n, double* x, double* P);
   void set_state(const int* slots, long n, const double* x, const double* P, const double* unwrap);
   long long n_measurements(long slot);
@@ -179,6 +188,17 @@ class Batch {
   // walked backwards lands on another XCD, whose L2 does not hold it (10^5 UA fp32: 4.7 -> 8.2 us per tick).
   bool zigzag() const { return state_bytes() >= zigzag_min_bytes(); }
   StepParams base_params() const;
+  void launch_step(const StepParams& p, hipStream_t st, int meas_rows = 7);   // ops_->step + the measured-pose rows when kept
+  bool keep_meas_ = false;
+  int host_meas_rows_ = 7;         // measurement rows the host SoA path transported for the tick being enqueued
+  double* d_lastmeas_ = nullptr;   // [cap_][7] doubles (measured_pose.hpp), null unless keep_meas_
+  std::vector<std::vector<double>> class_qr_;   // [Q | R] of every class as given (doubles)
+  static constexpr size_t kP0TableMax = 4096;
+  std::vector<std::vector<double>> p0_tab_;
+  std::unordered_map<std::string, int> p0_index_;
+  std::vector<int> slot_p0_;       // slot -> row of p0_tab_
+  bool p0_kept_ = true;
+  int intern_p0(const double* P0);
   char* d_rec_ = nullptr;          // the CURRENT records (A -> B ticks swap it with d_rec_alt_ after every launch)
   char* d_rec_alt_ = nullptr;      // second record buffer of the same capacity, allocated on the first A -> B tick
   char* alt_records();

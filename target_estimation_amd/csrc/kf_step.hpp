@@ -164,8 +164,15 @@ __device__ __forceinline__ void write_outputs_row(const T* x, long slot, double*
 #pragma unroll
   for (int c = 0; c < 6; ++c) o_acc[slot * 6 + c] = (double)acc6[c];
 }
+// ONE wavefront only: the launch has at most TPW entries (kf_ops_impl.hpp refuses o_pose with p.n > C::TPW), so "every row
+// of this launch" = "every lane of this wave".  Each lane makes its own rows visible to the host (system-scope fence), then
+// the lanes meet at a wave barrier -- an explicit ordering of the other lanes' fences before lane 0's store, instead of
+// relying on the wave running in lockstep -- and only then lane 0 publishes the sequence number the host spins on.
 __device__ __forceinline__ void signal_done(int* flag, int seq, int lane) {
   __threadfence_system();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (lane == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 

@@ -10,24 +10,16 @@
 #include <thread>
 
 #include "hip_check.hpp"
+#include "rccl_abi.hpp"
 #include "target_manager.hpp"
 
 namespace te {
 
 namespace {
-// the part of rccl.h this file needs (ABI of RCCL 2.x: /opt/rocm/include/rccl/rccl.h:43,187,220,467,700,722,923)
-struct UniqueId { char internal[PoseComm::kIdBytes]; };
-constexpr int kNcclDouble = 8;
-struct Rccl {
-  int (*GetUniqueId)(UniqueId*) = nullptr;
-  int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
-  int (*CommDestroy)(void*) = nullptr;
-  int (*GroupStart)() = nullptr;
-  int (*GroupEnd)() = nullptr;
-  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
-  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
-  const char* (*GetErrorString)(int) = nullptr;
-};
+using rccl_abi::UniqueId;
+using rccl_abi::Rccl;
+constexpr int kNcclDouble = rccl_abi::kNcclDouble;
+static_assert(sizeof(UniqueId) == PoseComm::kIdBytes, "the id the C ABI passes around is NCCL_UNIQUE_ID_BYTES long");
 
 const Rccl& rccl() {
   static Rccl r;

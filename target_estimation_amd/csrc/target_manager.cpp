@@ -22,7 +22,7 @@ TargetManager::TargetManager(int dtype, int lanes_per_target) : dtype_(dtype), l
   const char* v = std::getenv("TARGET_ESTIMATION_VERBOSE");
   verbose_ = v && v[0] && v[0] != '0';
   const char* ld = std::getenv("TARGET_ESTIMATION_LOG_DIR");
-  if (ld && ld[0]) log_dir_ = ld;
+  if (ld && ld[0]) { log_dir_ = ld; keep_meas_ = true; }   // batches created later inherit the measured-pose rows
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
     throw std::runtime_error("target_estimation_amd: no HIP device available; this library has no CPU path");
@@ -119,6 +119,7 @@ bool TargetManager::resolveOnDevice(const unsigned* ids, long n, ResolveCounters
 }
 
 TargetManager::~TargetManager() {
+  closeLogFiles();
   devIdsFree();
   dropSeqGraphs();
   for (auto st : branch_streams_) (void)hipStreamDestroy(st);
@@ -238,6 +239,7 @@ int TargetManager::findOrCreateBatch(int type, const double* Q, const double* R,
       return (int)b;
     }
   batches_.emplace_back(new Batch(type, dtype_, lanes_code, Q, R, stream_, &target_lock_));
+  if (keep_meas_) batches_.back()->set_keep_measurement(true);
   cls = 0;
   return (int)batches_.size() - 1;
 }
@@ -246,34 +248,187 @@ bool TargetManager::find(unsigned id, Loc& loc) {
   return targets_.find(id, loc);
 }
 
+namespace {
+// channel order of LogFiles::f / log_all_
+const char* const kLogChannel[7] = {"time", "meas_pose", "est_pose", "est_twist", "pose", "est_acc", "covariance"};
+
+// unit quaternion [x y z w] -> rotation matrix (row-major), Eigen's Quaterniond::toRotationMatrix
+void host_quat_to_rot(const double* q, double* R) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+  R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+// rotToRpy, geometry.hpp:191-196
+void host_rot_to_rpy(const double* R, double* rpy) {
+  rpy[0] = std::atan2(R[7], R[8]);
+  rpy[1] = std::atan2(-R[6], std::sqrt(R[7] * R[7] + R[8] * R[8]));
+  rpy[2] = std::atan2(R[3], R[0]);
+}
+// one row in writeTxtFile's format (utils.hpp:96-120: `myfile << value << " "` per column, then "\n"; default ostream
+// formatting = %g with 6 significant digits)
+void append_row(std::string& out, const double* v, long w) {
+  char buf[40];
+  for (long c = 0; c < w; ++c) {
+    std::snprintf(buf, sizeof buf, "%g ", v[c]);
+    out += buf;
+  }
+  out += "\n";
+}
+}  // namespace
+
+void TargetManager::closeLogFiles() {
+  for (auto& kv : log_files_)
+    for (std::FILE* f : kv.second.f) if (f) std::fclose(f);
+  log_files_.clear();
+  for (std::FILE*& f : log_all_) { if (f) std::fclose(f); f = nullptr; }
+}
+
+void TargetManager::setLogDirectory(const std::string& dir) {
+  {
+    lock_guard<mutex> lg(target_lock_);
+    closeLogFiles();
+    log_dir_ = dir;
+  }
+  if (!dir.empty()) setKeepMeasurement(true);   // the "measurement" channel needs the rows
+}
+
+void TargetManager::setLogTargets(const unsigned* ids, long n) {
+  lock_guard<mutex> lg(target_lock_);
+  closeLogFiles();
+  log_ids_.assign(ids, ids + (n > 0 ? n : 0));
+  std::sort(log_ids_.begin(), log_ids_.end());
+  log_ids_.erase(std::unique(log_ids_.begin(), log_ids_.end()), log_ids_.end());
+}
+
+void TargetManager::setKeepMeasurement(bool on) {
+  lock_guard<mutex> lg(target_lock_);
+  keep_meas_ = on;
+  for (auto& b : batches_) b->set_keep_measurement(on);
+  dropSeqGraphs();
+}
+
 void TargetManager::log() {
   if (log_dir_.empty()) return;
   lock_guard<mutex> lg(target_lock_);
-  for (auto& b : batches_) {
-    const long n = b->size();
+  // what to log: the explicit selection, or everything while the population is small
+  std::vector<unsigned> ids = log_ids_;
+  const bool per_target = !ids.empty() || (long)targets_.size() <= kLogAutoSelect;
+  if (ids.empty()) ids = targets_.sorted_ids();
+  // group the ids by batch (slot lists), keep the id order inside a batch
+  std::vector<std::vector<int>> slots(batches_.size());
+  std::vector<std::vector<unsigned>> who(batches_.size());
+  for (unsigned id : ids) {
+    Loc loc;
+    if (!find(id, loc)) continue;   // a selected target that does not exist (yet, or any more)
+    slots[(size_t)loc.batch].push_back(loc.slot);
+    who[(size_t)loc.batch].push_back(id);
+  }
+  std::string all[7];
+  for (size_t bi = 0; bi < batches_.size(); ++bi) {
+    Batch& b = *batches_[bi];
+    const long n = (long)slots[bi].size();
     if (!n) continue;
-    const int N = b->n_state();
-    std::vector<double> pose((size_t)n * 7), twist((size_t)n * 6), acc((size_t)n * 6), x((size_t)n * N), P((size_t)n * N * N);
-    b->outputs(nullptr, n, pose.data(), twist.data(), acc.data(), false, 0.0);
-    b->get_state(nullptr, n, x.data(), P.data());
-    std::vector<double> times((size_t)n);
-    b->times(times.data());
+    const int N = b.n_state();
+    std::vector<double> pose((size_t)n * 7), twist((size_t)n * 6), acc((size_t)n * 6), x((size_t)n * N), P((size_t)n * N * N), meas((size_t)n * 7);
+    b.outputs(slots[bi].data(), n, pose.data(), twist.data(), acc.data(), false, 0.0);
+    b.get_state(slots[bi].data(), n, x.data(), P.data());
+    if (b.keep_measurement()) b.measured_poses(slots[bi].data(), n, meas.data());
+    else for (long s = 0; s < n; ++s) for (int c = 0; c < 7; ++c) meas[(size_t)s * 7 + c] = c == 6 ? 1.0 : 0.0;
     for (long s = 0; s < n; ++s) {
-      const std::string id = std::to_string(b->slot_id(s));
-      auto row = [&](const char* name, const double* v, int w) {
-        std::ofstream f((log_dir_ + "/" + name + "_" + id).c_str(), std::ios::app);
-        for (int c = 0; c < w; ++c) f << v[c] << " ";
-        f << "\n";
-      };
-      row("time", &times[(size_t)s], 1);
-      row("est_pose", &pose[(size_t)s * 7], 7);
-      row("est_twist", &twist[(size_t)s * 6], 6);
-      row("est_acc", &acc[(size_t)s * 6], 6);
-      std::vector<double> diag((size_t)N);
-      for (int r = 0; r < N; ++r) diag[(size_t)r] = P[((size_t)s * N + r) * N + r];
-      row("cov_diag", diag.data(), N);
+      const unsigned id = who[bi][(size_t)s];
+      const double t = b.time(slots[bi][(size_t)s]);
+      double R[9], pose6[6];
+      host_quat_to_rot(&pose[(size_t)s * 7 + 3], R);
+      for (int c = 0; c < 3; ++c) pose6[c] = pose[(size_t)s * 7 + c];
+      host_rot_to_rpy(R, pose6 + 3);   // isometryToPose6d, geometry.hpp:602-608
+      const double* row[7] = {&t, &meas[(size_t)s * 7], &pose[(size_t)s * 7], &twist[(size_t)s * 6], pose6, &acc[(size_t)s * 6],
+                              &P[(size_t)s * N * N]};
+      const long width[7] = {1, 7, 7, 6, 6, 6, (long)N * N};
+      if (per_target) {
+        LogFiles& lf = log_files_[id];
+        for (int ch = 0; ch < 7; ++ch) {
+          if (!lf.f[ch]) {
+            lf.f[ch] = std::fopen((log_dir_ + "/" + kLogChannel[ch] + "_" + std::to_string(id)).c_str(), "a");
+            if (!lf.f[ch]) { std::cerr << "Unable to open file : [" << log_dir_ << "/" << kLogChannel[ch] << "_" << id << "]" << std::endl; continue; }
+          }
+          std::string line;
+          append_row(line, row[ch], width[ch]);
+          std::fwrite(line.data(), 1, line.size(), lf.f[ch]);   // one buffered write per channel per call ...
+        }
+      } else {
+        const double idd = (double)id;
+        for (int ch = 0; ch < 7; ++ch) {
+          char buf[24];
+          std::snprintf(buf, sizeof buf, "%g ", idd);
+          all[ch] += buf;
+          append_row(all[ch], row[ch], width[ch]);
+        }
+      }
     }
   }
+  if (per_target) {
+    for (auto& kv : log_files_)
+      for (std::FILE* f : kv.second.f) if (f) std::fflush(f);   // ... made visible to readers at the end of the call
+  } else {
+    for (int ch = 0; ch < 7; ++ch) {
+      if (!log_all_[ch]) log_all_[ch] = std::fopen((log_dir_ + "/" + kLogChannel[ch] + "_all").c_str(), "a");
+      if (!log_all_[ch]) continue;
+      std::fwrite(all[ch].data(), 1, all[ch].size(), log_all_[ch]);
+      std::fflush(log_all_[ch]);
+    }
+  }
+}
+
+bool TargetManager::getTargetMeasuredPose(unsigned id, double* pose7) {
+  lock_guard<mutex> lg(target_lock_);
+  Loc loc;
+  if (!find(id, loc) || !batches_[(size_t)loc.batch]->keep_measurement()) return false;
+  const int slot = loc.slot;
+  batches_[(size_t)loc.batch]->measured_poses(&slot, 1, pose7);
+  return true;
+}
+
+bool TargetManager::getTargetPeriodEstimate(unsigned id, double& period) {
+  double twist[6];
+  if (!getTargetTwist(id, twist)) return false;
+  const double omega_norm = std::sqrt(twist[3] * twist[3] + twist[4] * twist[4] + twist[5] * twist[5]);
+  period = omega_norm > 0 ? 2 * M_PI / omega_norm : -1.0;   // target_interface.cpp:82-86
+  return true;
+}
+
+bool TargetManager::getTargetTransform(unsigned id, double* T) {
+  double pose[7];
+  if (!getTargetPose(id, pose)) return false;
+  double R[9];
+  host_quat_to_rot(pose + 3, R);
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) T[r * 4 + c] = R[r * 3 + c];
+    T[r * 4 + 3] = pose[r];
+  }
+  T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
+  return true;
+}
+
+bool TargetManager::getTargetDims(unsigned id, int& n, int& m) {
+  lock_guard<mutex> lg(target_lock_);
+  Loc loc;
+  if (!find(id, loc)) return false;
+  n = batches_[(size_t)loc.batch]->n_state();
+  m = batches_[(size_t)loc.batch]->n_meas();
+  return true;
+}
+
+bool TargetManager::getTargetModelMatrices(unsigned id, double* Q, double* R, double* P0) {
+  lock_guard<mutex> lg(target_lock_);
+  Loc loc;
+  if (!find(id, loc)) return false;
+  Batch& b = *batches_[(size_t)loc.batch];
+  if (Q || R) b.class_matrices(loc.slot, Q, R);
+  if (P0 && !b.initial_covariance(loc.slot, P0)) return false;
+  return true;
 }
 
 std::vector<unsigned> TargetManager::getAvailableTargets() {
@@ -484,6 +639,11 @@ bool TargetManager::erase(unsigned id) {
   targets_.erase(id);
   dev_ids_.dirty = true;
   if (!was_last) targets_.set(moved, Loc{loc.batch, loc.slot});
+  auto lf = log_files_.find(id);   // a logged target that goes away closes its files (a later target of that id appends)
+  if (lf != log_files_.end()) {
+    for (std::FILE* f : lf->second.f) if (f) std::fclose(f);
+    log_files_.erase(lf);
+  }
   return true;
 }
 
@@ -1018,7 +1178,9 @@ void TargetManager::stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpe
           set_deps(none);                                  // a new chain: no predecessor
           const bool zz = batches_[b]->state_bytes() >= Batch::zigzag_min_bytes();
           for (long s = 0; s < n_ticks; ++s) batches_[b]->enqueue_tick(cap, s, dt, specs[b], query, org, radius, zz && (s & 1) != 0);
+#ifdef TE_TEST_HOOKS   // only in libtarget_estimation_amd_testhooks.so (csrc/Makefile `testhooks`), never in the product library
           if (std::getenv("TE_TEST_FAIL_IN_CAPTURE")) throw std::runtime_error("target_estimation_amd: injected failure inside stream capture");
+#endif
           const Nodes tail = captured();
           leaves.insert(leaves.end(), tail.begin(), tail.end());
         }

@@ -17,7 +17,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <functional>
+#include <unordered_map>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -60,14 +62,36 @@ class TargetManager {
   bool getTargetTwist(unsigned id, double* twist6);         // :263-272
   bool getTargetAcceleration(unsigned id, double* acc6);    // :274-283
   long long getNumberMeasurements(unsigned id);             // :285-295
-  // :120-124.  The reference publishes measurement / pose / twist / acceleration / covariance of every
-  // target through rt_logger (an external ROS package, target_interface.cpp:32-55), out of scope here.
-  // Equivalent observability without ROS: if a log directory is set (setLogDirectory or env
-  // TARGET_ESTIMATION_LOG_DIR), every log() appends one row per target to <dir>/time_<id>,
-  // est_pose_<id>, est_twist_<id>, est_acc_<id>, cov_diag_<id> in the space-separated text format of
-  // writeTxtFile (utils.hpp:96-120) that matlab/plot_target_manager_test.m reads.  Otherwise a no-op.
+  // :120-124.  The reference publishes five channels per target through rt_logger (an external ROS package):
+  // measurement (measured_pose_), pose (pose_internal_ = [xyz rpy]), twist, acceleration, covariance (the full P),
+  // target_interface.cpp:32-40,50-55.  Equivalent observability without ROS: with a log directory set (setLogDirectory
+  // or env TARGET_ESTIMATION_LOG_DIR) every log() appends one row per SELECTED target to <dir>/
+  //   time_<id>  meas_pose_<id>  est_pose_<id>  est_twist_<id>      the files the reference's test writes and its plot script
+  //                                                                  loads (test/target_manager_test.cpp:164-168,
+  //                                                                  matlab/plot_target_manager_test.m:9-13)
+  //   pose_<id>  est_acc_<id>  covariance_<id>                       the remaining rt_logger channels ([xyz rpy]; acc6; P row-major)
+  // in writeTxtFile's text format (utils.hpp:96-120: values separated by one space, one row per line).  Selected =
+  // setLogTargets(ids), or every target while the manager holds at most kLogAutoSelect of them; the files stay open
+  // between calls and each gets ONE buffered write per call.  A larger population without a selection gets one file per
+  // channel, <channel>_all, rows prefixed by the id -- one write per channel per call.  Without a directory: a no-op, as
+  // the reference without LOGGER_ON.  Setting a directory switches the measured-pose rows on (setKeepMeasurement).
   void log();
-  void setLogDirectory(const std::string& dir) { log_dir_ = dir; }
+  void setLogDirectory(const std::string& dir);
+  void setLogTargets(const unsigned* ids, long n);   // n == 0: back to the automatic selection
+  static constexpr long kLogAutoSelect = 64;
+  // TargetInterface::getMeasuredPose (target_interface.cpp:117-121): kept only on request (measured_pose.hpp)
+  void setKeepMeasurement(bool on);
+  bool keepMeasurement() const { return keep_meas_; }
+  bool getTargetMeasuredPose(unsigned id, double* pose7);          // false: unknown id or not kept
+  // TargetInterface::getPeriodEstimate (target_interface.cpp:80-87): 2 pi / |omega| of the current twist, -1 if not rotating
+  bool getTargetPeriodEstimate(unsigned id, double& period);
+  // TargetInterface::getEstimatedTransform (target_interface.cpp:95-98): T_ as a row-major 4x4 [R t; 0 1]
+  bool getTargetTransform(unsigned id, double* T16);
+  // getN() / getM() (target_interface.hpp:142,148)
+  bool getTargetDims(unsigned id, int& n, int& m);
+  // getTarget(id)->getEstimator()->getQ() / getR() / getP0() (kalman.hpp:74-89), row-major doubles as given at init;
+  // any pointer may be null.  false: unknown id (or, for P0 only, more distinct P0 matrices than the host mirror keeps)
+  bool getTargetModelMatrices(unsigned id, double* Q, double* R, double* P0);
   std::vector<unsigned> getAvailableTargets();              // :126-133
   bool selectTargetType(const std::string& type_str, target_t& type);  // :52-65
 
@@ -164,6 +188,12 @@ class TargetManager {
   bool verbose_ = false;
   int filters_length_ = 250;
   std::string log_dir_;
+  bool keep_meas_ = false;
+  std::vector<unsigned> log_ids_;                       // explicit selection (sorted); empty = automatic
+  struct LogFiles { std::FILE* f[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; };
+  std::unordered_map<unsigned, LogFiles> log_files_;    // per selected target, kept open
+  std::FILE* log_all_[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  void closeLogFiles();
   // recorded all-batches sequences (stepSequenceAll)
   struct SeqGraph {
     long n_ticks; double dt; bool query; double origin[3]; double radius;

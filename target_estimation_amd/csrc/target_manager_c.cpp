@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/target_estimation_amd/target_batch_c.h"
+#include "intersection_solver.hpp"
 #include "measurement_ingest.hpp"
 #include "pose_gather.hpp"
 #include "stream_gen.hpp"
@@ -510,6 +511,67 @@ long target_ingest_tick(target_ingest_c* ingest, double dt, double now, unsigned
     }
   });
   return n;
+}
+
+// ---------------------------------------------------------------- IntersectionSolver as an object
+target_intersection_solver_c* target_intersection_solver_new(target_manager_c* manager, unsigned int filters_length) {
+  te::IntersectionSolver* sv = nullptr;
+  guarded("target_intersection_solver_new", [&] { sv = new te::IntersectionSolver(M(manager), filters_length); });
+  return (target_intersection_solver_c*)sv;
+}
+void target_intersection_solver_delete(target_intersection_solver_c* solver) { delete (te::IntersectionSolver*)solver; }
+double target_intersection_solver_get_time_with_sphere(target_intersection_solver_c* solver, unsigned int id, double t1,
+                                                        const double* origin, double radius) {
+  return guarded_value<double>("target_intersection_solver_get_time_with_sphere", -1.0, [&] {
+    if (!solver || !origin) throw std::invalid_argument("NULL argument");
+    return ((te::IntersectionSolver*)solver)->getIntersectionTimeWithSphere(id, t1, origin, radius);
+  });
+}
+bool target_intersection_solver_get_pose_with_sphere(target_intersection_solver_c* solver, unsigned int id, double t1, double pos_th,
+                                                     double ang_th, const double* origin, double radius, double* pose7) {
+  return guarded_value<bool>("target_intersection_solver_get_pose_with_sphere", false, [&] {
+    if (!solver || !origin || !pose7) throw std::invalid_argument("NULL argument");
+    return ((te::IntersectionSolver*)solver)->getIntersectionPoseWithSphere(id, t1, pos_th, ang_th, origin, radius, pose7);
+  });
+}
+void target_intersection_solver_last_errors(target_intersection_solver_c* solver, double* pos_error_filtered, double* ang_error_filtered) {
+  if (!solver) return;
+  if (pos_error_filtered) *pos_error_filtered = ((te::IntersectionSolver*)solver)->lastPositionErrorFiltered();
+  if (ang_error_filtered) *ang_error_filtered = ((te::IntersectionSolver*)solver)->lastAngleErrorFiltered();
+}
+
+// ---------------------------------------------------------------- TargetInterface / estimator getters
+int target_manager_set_keep_measurement(target_manager_c* self, int on) {
+  return guarded("target_manager_set_keep_measurement", [&] { M(self)->setKeepMeasurement(on != 0); });
+}
+bool target_manager_get_measured_pose(target_manager_c* self, unsigned int id, double* pose7) {
+  return guarded_value<bool>("target_manager_get_measured_pose", false, [&] { return M(self)->getTargetMeasuredPose(id, pose7); });
+}
+bool target_manager_get_period_estimate(target_manager_c* self, unsigned int id, double* period) {
+  return guarded_value<bool>("target_manager_get_period_estimate", false, [&] {
+    double p = -1.0;
+    const bool ok = M(self)->getTargetPeriodEstimate(id, p);
+    if (ok && period) *period = p;
+    return ok;
+  });
+}
+bool target_manager_get_estimated_transform(target_manager_c* self, unsigned int id, double* T16) {
+  return guarded_value<bool>("target_manager_get_estimated_transform", false, [&] { return M(self)->getTargetTransform(id, T16); });
+}
+int target_manager_get_n(target_manager_c* self, unsigned int id) {
+  return guarded_value<int>("target_manager_get_n", -1, [&] { int n = 0, m = 0; return M(self)->getTargetDims(id, n, m) ? n : 0; });
+}
+int target_manager_get_m(target_manager_c* self, unsigned int id) {
+  return guarded_value<int>("target_manager_get_m", -1, [&] { int n = 0, m = 0; return M(self)->getTargetDims(id, n, m) ? m : 0; });
+}
+bool target_manager_get_model_matrices(target_manager_c* self, unsigned int id, double* Q, double* R, double* P0) {
+  return guarded_value<bool>("target_manager_get_model_matrices", false, [&] { return M(self)->getTargetModelMatrices(id, Q, R, P0); });
+}
+int target_manager_set_log_targets(target_manager_c* self, const unsigned int* ids, long n) {
+  return guarded("target_manager_set_log_targets", [&] {
+    if (n > 0 && !ids) throw std::invalid_argument("NULL id list");
+    M(self)->setLogTargets(ids, n);
+  });
 }
 
 // ---------------------------------------------------------------- synthetic measurement streams

@@ -313,6 +313,41 @@ class TargetManager:
         _check(self._lib.target_manager_set_log_directory(self._h, None if path is None else str(path).encode()),
                "target_manager_set_log_directory")
 
+    def set_log_targets(self, ids):
+        ids, idp = _ids(ids if ids is not None else [])
+        _check(self._lib.target_manager_set_log_targets(self._h, idp, len(ids)), "target_manager_set_log_targets")
+
+    def set_keep_measurement(self, on=True):
+        _check(self._lib.target_manager_set_keep_measurement(self._h, 1 if on else 0), "target_manager_set_keep_measurement")
+
+    # TargetInterface getters reached through getTarget(id)-> in the reference (target_interface.hpp:94-148)
+    def getMeasuredPose(self, id):
+        return self._get1(self._lib.target_manager_get_measured_pose, id, 7)
+
+    def getPeriodEstimate(self, id):
+        p = C.c_double(float("nan"))
+        ok = self._lib.target_manager_get_period_estimate(self._h, int(id), C.byref(p))
+        return p.value if ok else None
+
+    def getEstimatedTransform(self, id):
+        ok, T = self._get1(self._lib.target_manager_get_estimated_transform, id, 16)
+        return bool(ok), T.reshape(4, 4)
+
+    def getN(self, id):
+        return self._lib.target_manager_get_n(self._h, int(id))
+
+    def getM(self, id):
+        return self._lib.target_manager_get_m(self._h, int(id))
+
+    def getModelMatrices(self, id):
+        """(Q, R, P0) the target was created with (getEstimator()->getQ / getR / getP0), or None for an unknown id."""
+        n, m = self.getN(id), self.getM(id)
+        if n <= 0:
+            return None
+        Q, R, P0 = np.empty((n, n)), np.empty((m, m)), np.empty((n, n))
+        ok = self._lib.target_manager_get_model_matrices(self._h, int(id), _dp(Q), _dp(R), _dp(P0))
+        return (Q, R, P0) if ok else None
+
     def size(self):
         return self._lib.target_manager_size(self._h)
 

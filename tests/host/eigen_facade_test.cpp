@@ -18,6 +18,7 @@
 
 using target_estimation_amd::TargetManager;
 
+
 static int fails = 0;
 #define CHECK(c) do { if (!(c)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); ++fails; } } while (0)
 
@@ -114,6 +115,57 @@ int main(int argc, char** argv) {
   Eigen::Vector3d origin;
   origin(0) = 0; origin(1) = 0; origin(2) = 0;
   CHECK(mgr.getIntersectionTimeWithSphere(11, 0.5, origin, 10.0) == -1.0);   // uniform_velocity never intersects (intersection_solver.cpp:61-63)
+  // the round-3 getters of TargetInterface / the estimator (target_interface.hpp:94-148, kalman.hpp:74-89)
+  if (h) {
+    double per = 0, T16[16], q_back[36], r_back[9], p_back[36];
+    CHECK(target_manager_get_period_estimate(c, 11, &per) && h->getPeriodEstimate() == per && per == -1.0);   // no angular rate in this model
+    CHECK(target_manager_get_estimated_transform(c, 11, T16));
+    const Eigen::Isometry3d T = h->getEstimatedTransform();
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) CHECK(T.matrix()(i, j) == T16[i * 4 + j]);
+    CHECK(T.matrix()(0, 3) == h->getEstimatedPose()(0) && T.matrix()(0, 0) == 1.0 && T.matrix()(3, 3) == 1.0);
+    CHECK(h->getN() == 6 && h->getM() == 3);
+    CHECK(target_manager_get_model_matrices(c, 11, q_back, r_back, p_back));
+    const Eigen::MatrixXd Qb = h->getEstimator()->getQ(), Rb = h->getEstimator()->getR(), Pb0 = h->getEstimator()->getP0();
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j) CHECK(Qb(i, j) == Q(i, j) && Pb0(i, j) == P0(i, j) && q_back[i * n + j] == Q(i, j));
+    for (int i = 0; i < m; ++i)
+      for (int j = 0; j < m; ++j) CHECK(Rb(i, j) == R(i, j));
+    const Eigen::Vector7d mp = h->getMeasuredPose();     // not kept by default: the initial pose
+    CHECK(mp(6) == 1.0 && mp(0) == 0.0);
+  }
+  // IntersectionSolver with the reference's constructor and method signatures (intersection_solver.hpp:63,73,86)
+  {
+    TargetManager::Ptr shared(new TargetManager(argv[1]));
+    shared->setKeepMeasurement(true);
+    Eigen::MatrixXd Qa = Eigen::MatrixXd::Zero(9, 9), Pa = Eigen::MatrixXd::Zero(9, 9), Ra = Eigen::MatrixXd::Zero(3, 3);
+    for (int i = 0; i < 9; ++i) { Qa(i, i) = 1e-6; Pa(i, i) = 1e-2; }
+    for (int i = 0; i < 3; ++i) Ra(i, i) = 1e-4;
+    Eigen::Vector7d start = Eigen::Vector7d::Zero();
+    start(0) = 10.0; start(6) = 1.0;
+    Eigen::Vector6d vin = Eigen::Vector6d::Zero(), ain = Eigen::Vector6d::Zero();
+    vin(0) = -4.0; ain(0) = -1.0;                       // inbound and accelerating towards the origin
+    shared->init(TargetManager::UNIFORM_ACCELERATION, 5, dt, 0.0, Qa, Ra, Pa, start, vin, ain);
+    target_estimation_amd::IntersectionSolver solver(shared, 3), solver_default(shared);
+    Eigen::Vector7d ip;
+    bool conv = false, conv_any = false;
+    for (int s = 0; s < 12; ++s) {
+      const double t = dt * (s + 1);
+      Eigen::Vector7d z = start;
+      z(0) = 10.0 - 4.0 * t - 0.5 * t * t;
+      CHECK(shared->update(5, dt, z));
+      const double d = solver.getIntersectionTimeWithSphere(5, t, origin, 2.0);
+      CHECK(d > 0 && d == target_manager_get_intersection_time_with_sphere(shared->handle(), 5, t, origin.data(), 2.0));
+      conv = solver.getIntersectionPoseWithSphere(5, t, 0.05, 0.05, origin, 2.0, ip);
+      conv_any = conv_any || conv;
+      CHECK(std::fabs(std::sqrt(ip(0) * ip(0) + ip(1) * ip(1) + ip(2) * ip(2)) - 2.0) < 1e-6);   // the pose is ON the sphere
+      if (s == 0) CHECK(!conv);                          // first pose vs initPose: 2 m apart
+    }
+    CHECK(conv_any && conv);                             // the intersection point settles: the filtered error falls below 5 cm
+    CHECK(!solver_default.getIntersectionPoseWithSphere(99, 0.1, 0.05, 0.05, origin, 2.0, ip) && ip(6) == 1.0 && ip(0) == 0.0);
+    const Eigen::Vector7d last = shared->getTarget(5)->getMeasuredPose();
+    CHECK(last(0) == 10.0 - 4.0 * (dt * 12) - 0.5 * (dt * 12) * (dt * 12));
+  }
   mgr.update(dt);   // all targets, predict only
   CHECK(std::fabs(mgr.getTarget(12)->getTime() - 41 * dt) < 1e-12);
   CHECK(mgr.erase(12) && !mgr.erase(12));

@@ -84,3 +84,12 @@ def test_null_handles_are_errors_not_crashes(capfd):
     assert lib.target_manager_size(None) < 0
     assert b"NULL" in lib.target_manager_last_error()
     assert "NULL manager handle" in capfd.readouterr().err
+
+
+def test_hand_declared_rccl_abi_matches_the_installed_header():
+    """pose_gather.cpp resolves RCCL with dlsym and declares its ABI by hand (csrc/rccl_abi.hpp); the multi-rank exchange has
+    never run on hardware the builder has (one GPU).  This holds the declarations to /opt/rocm/include/rccl/rccl.h with
+    static_asserts: datatype code, id size / alignment, every entry point's parameter list."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "host", "rccl_abi_check.cpp")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-fsyntax-only", "-x", "hip", "--offload-host-only", "-I", "/opt/rocm/include", src])

@@ -98,6 +98,6 @@ def test_log_snapshots(tmp_path, models):
     assert est.shape == (3, 7)
     pose, _, _, _ = mgr.get_est_batch(ids)
     np.testing.assert_allclose(est[-1], pose[1], rtol=1e-5)
-    assert np.loadtxt(tmp_path / "cov_diag_4").shape == (3, 9)
+    assert np.loadtxt(tmp_path / "covariance_4").shape == (3, 81) and np.loadtxt(tmp_path / "meas_pose_4").shape == (3, 7)
     np.testing.assert_allclose(np.loadtxt(tmp_path / "time_4"), [0.004, 0.008, 0.012], rtol=1e-9)
     mgr.close()

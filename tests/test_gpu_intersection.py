@@ -229,3 +229,67 @@ def test_gate_moving_averages_meet_the_reference_filter_test(models):
     assert np.abs(variance[0] - 1.0) < 0.1               # avg_filter_test.cpp:41
     assert np.abs(variance - 1.0).max() < 0.2
     mgr.close()
+
+
+@pytest.mark.parametrize("name", ["uniform_acceleration", "angular_rates"])
+def test_intersection_solver_object_has_one_gate_like_the_reference(models, name):
+    """The reference's IntersectionSolver is an OBJECT with ONE gate (two moving averages + the previous pose) shared by every
+    id queried through it (intersection_solver.hpp:56-126, src/intersection_solver.cpp:19-40,91-124).  C entry points
+    target_intersection_solver_*: three targets queried in turn through one solver every tick, against ONE oracle gate fed
+    in the same order; a second solver on the same manager has its own, independent gate."""
+    import ctypes as C
+    from target_estimation_amd import capi
+    lib = capi.lib()
+    m = models[name]
+    N, dt, W = 3, 0.004, 5
+    p0, v0, a0 = scene(N, 9)
+    ids = np.array([7, 3, 50], dtype=np.uint32)
+    mgr = te.TargetManager(model_path(name))
+    mgr.init_batch(ids, dt, 0.0, p0, v0, a0)
+    orc = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], p0, dt, 0.0, v0, a0)
+    gate, gate2 = oracle.OracleGate(1, W), oracle.OracleGate(1, 250)
+    s1 = lib.target_intersection_solver_new(mgr.handle, W)
+    s2 = lib.target_intersection_solver_new(mgr.handle, 250)       # the reference's default window
+    assert s1 and s2
+    origin, radius, pos_th, ang_th = np.zeros(3), 5.0, 0.03, 0.03
+    op = origin.ctypes.data_as(capi.c_double_p)
+    rng = np.random.default_rng(4)
+    seen = {True: 0, False: 0}
+    pf, af = C.c_double(), C.c_double()
+    for s in range(25):
+        t = (s + 1) * dt
+        meas = p0.copy()
+        meas[:, :3] = p0[:, :3] + v0[:, :3] * t + 0.5 * a0[:, :3] * t * t + rng.normal(0, 0.01, (N, 3))
+        mgr.update_batch(ids, dt, meas)
+        orc.step(dt, meas)
+        ok_o, pose_o, delta_o = orc.intersection_pose(t, origin, radius)
+        for i in range(N):
+            pose = np.full(7, np.nan)
+            conv = lib.target_intersection_solver_get_pose_with_sphere(s1, int(ids[i]), t, pos_th, ang_th, op, radius,
+                                                                       pose.ctypes.data_as(capi.c_double_p))
+            conv_o, pf_o, af_o = gate.update(ok_o[i:i + 1], pose_o[i:i + 1], pos_th, ang_th)
+            d = lib.target_intersection_solver_get_time_with_sphere(s1, int(ids[i]), t, op, radius)
+            assert (d > -1) == bool(ok_o[i])
+            if ok_o[i]:
+                assert d == pytest.approx(delta_o[i], rel=1e-8, abs=1e-10)
+                np.testing.assert_allclose(pose, pose_o[i], atol=1e-7)
+                lib.target_intersection_solver_last_errors(s1, C.byref(pf), C.byref(af))
+                assert pf.value == pytest.approx(pf_o[0], rel=1e-6, abs=1e-9) and af.value == pytest.approx(af_o[0], rel=1e-6, abs=1e-7)
+                if abs(pf_o[0] - pos_th) > 1e-7 and abs(af_o[0] - ang_th) > 1e-6:
+                    assert bool(conv) == bool(conv_o[0])
+                    seen[bool(conv)] += 1
+            else:
+                np.testing.assert_array_equal(pose, [0, 0, 0, 0, 0, 0, 1.0])      # initPose(intersection_pose), :99
+                assert not conv
+        # the second solver sees target 7 only: its gate is its own
+        pose = np.zeros(7)
+        conv2 = lib.target_intersection_solver_get_pose_with_sphere(s2, 7, t, pos_th, ang_th, op, radius, pose.ctypes.data_as(capi.c_double_p))
+        conv2_o, pf2_o, _ = gate2.update(ok_o[0:1], pose_o[0:1], pos_th, ang_th)
+        if ok_o[0] and abs(pf2_o[0] - pos_th) > 1e-7:
+            assert bool(conv2) == bool(conv2_o[0])
+    assert seen[True] > 0 and seen[False] > 0        # jumping between three targets keeps the shared gate open at first
+    assert lib.target_intersection_solver_get_time_with_sphere(s1, 12345, 0.1, op, radius) == -1.0     # unknown id
+    lib.target_intersection_solver_delete(s1)
+    lib.target_intersection_solver_delete(s2)
+    assert not lib.target_intersection_solver_new(None, 5)
+    mgr.close()
