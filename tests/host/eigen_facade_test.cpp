@@ -144,7 +144,9 @@ int main(int argc, char** argv) {
     Eigen::Vector7d start = Eigen::Vector7d::Zero();
     start(0) = 10.0; start(6) = 1.0;
     Eigen::Vector6d vin = Eigen::Vector6d::Zero(), ain = Eigen::Vector6d::Zero();
-    vin(0) = -4.0; ain(0) = -1.0;                       // inbound and accelerating towards the origin
+    // inbound and decelerating: x(d) = 10 - 5 d + d^2 / 2 crosses +-2 at d = 2, 4, 6, 8 -- every real root of the quartic is
+    // positive (the reference takes the smallest real root BY VALUE and answers -1 if that is negative, intersection_solver.cpp:83)
+    vin(0) = -5.0; ain(0) = 1.0;
     shared->init(TargetManager::UNIFORM_ACCELERATION, 5, dt, 0.0, Qa, Ra, Pa, start, vin, ain);
     target_estimation_amd::IntersectionSolver solver(shared, 3), solver_default(shared);
     Eigen::Vector7d ip;
@@ -152,10 +154,10 @@ int main(int argc, char** argv) {
     for (int s = 0; s < 12; ++s) {
       const double t = dt * (s + 1);
       Eigen::Vector7d z = start;
-      z(0) = 10.0 - 4.0 * t - 0.5 * t * t;
+      z(0) = 10.0 - 5.0 * t + 0.5 * t * t;
       CHECK(shared->update(5, dt, z));
       const double d = solver.getIntersectionTimeWithSphere(5, t, origin, 2.0);
-      CHECK(d > 0 && d == target_manager_get_intersection_time_with_sphere(shared->handle(), 5, t, origin.data(), 2.0));
+      CHECK(std::fabs(d - (2.0 - t)) < 0.05 && d == target_manager_get_intersection_time_with_sphere(shared->handle(), 5, t, origin.data(), 2.0));
       conv = solver.getIntersectionPoseWithSphere(5, t, 0.05, 0.05, origin, 2.0, ip);
       conv_any = conv_any || conv;
       CHECK(std::fabs(std::sqrt(ip(0) * ip(0) + ip(1) * ip(1) + ip(2) * ip(2)) - 2.0) < 1e-6);   // the pose is ON the sphere
@@ -164,7 +166,7 @@ int main(int argc, char** argv) {
     CHECK(conv_any && conv);                             // the intersection point settles: the filtered error falls below 5 cm
     CHECK(!solver_default.getIntersectionPoseWithSphere(99, 0.1, 0.05, 0.05, origin, 2.0, ip) && ip(6) == 1.0 && ip(0) == 0.0);
     const Eigen::Vector7d last = shared->getTarget(5)->getMeasuredPose();
-    CHECK(last(0) == 10.0 - 4.0 * (dt * 12) - 0.5 * (dt * 12) * (dt * 12));
+    CHECK(last(0) == 10.0 - 5.0 * (dt * 12) + 0.5 * (dt * 12) * (dt * 12));
   }
   mgr.update(dt);   // all targets, predict only
   CHECK(std::fabs(mgr.getTarget(12)->getTime() - 41 * dt) < 1e-12);

@@ -591,4 +591,3 @@ def test_a_failure_inside_stream_capture_leaves_no_capture_behind():
     blob = open(_build.DEFAULT_LIB, "rb").read()
     assert b"TE_TEST_FAIL_IN_CAPTURE" not in blob and b"TE_TEST_FAIL_IN_CAPTURE" in open(lib, "rb").read()
     del ctypes
-    ref.close(); mgr.close()

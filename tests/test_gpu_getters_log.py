@@ -69,7 +69,7 @@ def test_target_interface_getters_match_the_oracle(models, name, dtype):
         ok, T = mgr.getEstimatedTransform(int(ids[i]))
         assert ok
         np.testing.assert_allclose(T, To[i], **tol)
-        np.testing.assert_allclose(T[:3, :3] @ T[:3, :3].T, np.eye(3), atol=1e-12)
+        np.testing.assert_allclose(T[:3, :3] @ T[:3, :3].T, np.eye(3), atol=1e-12 if dtype == "f64" else 1e-6)
         assert mgr.getN(int(ids[i])) == n and mgr.getM(int(ids[i])) == mm
     if name in ("uniform_velocity", "uniform_acceleration"):
         assert (po == -1.0).all()                             # these models never rotate (twist angular part is zero)

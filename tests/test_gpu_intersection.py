@@ -287,7 +287,18 @@ def test_intersection_solver_object_has_one_gate_like_the_reference(models, name
         conv2_o, pf2_o, _ = gate2.update(ok_o[0:1], pose_o[0:1], pos_th, ang_th)
         if ok_o[0] and abs(pf2_o[0] - pos_th) > 1e-7:
             assert bool(conv2) == bool(conv2_o[0])
-    assert seen[True] > 0 and seen[False] > 0        # jumping between three targets keeps the shared gate open at first
+    assert seen[False] > 0 and seen[True] == 0       # jumping between three targets metres apart keeps the SHARED gate open ...
+    # ... and staying on one target closes it once the window holds only that target's (small) errors
+    t = 25 * dt
+    ok_o, pose_o, _ = orc.intersection_pose(t, origin, radius)
+    assert ok_o[1]
+    last = None
+    for k in range(2 * W):
+        pose = np.zeros(7)
+        last = lib.target_intersection_solver_get_pose_with_sphere(s1, int(ids[1]), t, pos_th, ang_th, op, radius, pose.ctypes.data_as(capi.c_double_p))
+        conv_o, pf_o, af_o = gate.update(ok_o[1:2], pose_o[1:2], pos_th, ang_th)
+        assert bool(last) == bool(conv_o[0])
+    assert last
     assert lib.target_intersection_solver_get_time_with_sphere(s1, 12345, 0.1, op, radius) == -1.0     # unknown id
     lib.target_intersection_solver_delete(s1)
     lib.target_intersection_solver_delete(s2)
