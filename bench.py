@@ -126,7 +126,7 @@ MIXED = {
 }
 HEADLINE = "cfg4_1gpu"
 
-DEFAULT_EXTRA = ("cfg2,cfg2_stream,cfg3,cfg3_stream,cfg4,cfg4_64,cfg5,cfg4_1gpu32,cfg5_1gpu,cfg5_1gpu64,"
+DEFAULT_EXTRA = ("cfg2,cfg2_live,cfg2_stream,cfg3,cfg3_live,cfg3_stream,cfg4,cfg4_64,cfg5,cfg4_1gpu32,cfg5_1gpu,cfg5_1gpu64,"
                  "uv1m,uv1m32,ua1m64,ua1m,av1m64,av1m,ar1m64,ar1m,"
                  "uv10m,ua10m,av4m64,ar4m64,av8m,ar8m,cfg4_4m,"
                  "ar1m_a90,av1m_a90,ar1m64_1kcls,ar1m64_1kcls_rand,ar100k64_1kcls,uv1m_1kcls,uv1m_full,uv1m_packed,ar1m_full,ar1m_packed,av1m_packed,ar1m64_full,av1m64_full,ar1m64_packed,av1m64_packed")
@@ -266,7 +266,7 @@ def run_workload(te, torch, name, steps, warmup, lanes=0, targets=None, dist=Non
     # The synthetic measurements live in HBM as a ring of `ticks` ticks that the run cycles through.  Graph mode: every
     # gb-tick block of the ring is one recorded hipGraph.  Large batches: the ring is capped at RING_BYTES.
     gb = block_ticks(steps)
-    if launch_mode == "graph":
+    if launch_mode in ("graph", "live"):
         ring_want = RINGS.get(name, stream_ticks)
         ticks = max(gb, min(ring_want, steps + warmup) // gb * gb)
     else:
@@ -322,6 +322,8 @@ def run_workload(te, torch, name, steps, warmup, lanes=0, targets=None, dist=Non
             done[0] += blk
             count -= blk
 
+    if launch_mode == "live":
+        return run_live(te, torch, name, desc, model, dtype, mgr, b, meas, has, ids, dt, n_targets, world, steps, warmup, reps, ticks)
     if launch_mode == "graph":
         for off in range(0, ticks - gb + 1, gb):   # record every block's graph now (set-up; launches nothing)
             b.step_sequence(dt, meas[off:off + gb], None if has is None else has[off:off + gb], use_graph=2)
@@ -344,6 +346,66 @@ def run_workload(te, torch, name, steps, warmup, lanes=0, targets=None, dist=Non
         res["_mgr"] = (mgr, b, meas, ids, dt)
     else:
         mgr.close()
+    return res
+
+
+def run_live(te, torch, name, desc, model, dtype, mgr, b, meas, has, ids, dt, n_targets, world, steps, warmup, reps, ring_ticks):
+    """Resident ("live") mode (target_batch_live_*): ONE launch holds the batch's state in registers; the host posts one tick per
+    doorbell.  Two figures, both with exactly one tick per doorbell, neither is ever `value`:
+      back_to_back  the host posts the K doorbells without waiting (as the per-tick launches of the other modes are enqueued
+                    without waiting) and the region ends when every wavefront has finished tick K
+      paced         the next doorbell is posted only after the previous tick's completion was seen on the host (a full
+                    host <-> device round trip per tick: the latency of a stream with one tick in flight)
+    The ring was filled in advance (it cycles); wall clock only -- there is no launch boundary to put device events on, and a
+    device-wide synchronise would wait for the session."""
+    import numpy as np
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    mgr.set_stream(side.cuda_stream)     # a non-blocking stream of its own: nothing else may queue behind the resident kernel
+    b.live_start(dt, meas, has, max_ticks=1 << 30, idle_limit_s=10.0)
+    posted = [0]
+
+    def back_to_back(count):
+        b.live_post_each(count)
+        posted[0] += count
+        if not b.live_wait(posted[0], 20.0):
+            raise RuntimeError("live session stalled at %d of %d" % (b.live_done(), posted[0]))
+
+    def paced(count):
+        for _ in range(count):
+            b.live_post(1)
+            posted[0] += 1
+            if not b.live_wait(posted[0], 20.0):
+                raise RuntimeError("live session stalled")
+
+    def timed(fn, k, r):
+        out = []
+        for _ in range(r):
+            t0 = time.perf_counter()
+            fn(k)
+            out.append(time.perf_counter() - t0)
+        return out
+    back_to_back(max(warmup, 64))
+    k = max(steps, 4096)                  # a region of a few milliseconds
+    wall = timed(back_to_back, k, max(reps, 5))
+    wall_paced = timed(paced, min(k, 2000), 3)
+    served = b.live_stop()
+    assert served == posted[0]
+    x, P = mgr.get_state_batch(ids[:64])
+    assert np.isfinite(x).all() and np.isfinite(P).all()
+    res = summarize(name, desc, [model], dtype, [b], [kernel_name(b, model) + " (LIVE variant)"], n_targets, world, k, wall, [w * 1e3 for w in wall],
+                    "live: one resident launch, one tick per doorbell, back to back")
+    res.update(measurement_ring_ticks=ring_ticks, measurement_ring_bytes=int(meas.numel() * meas.element_size()),
+               survey_full_P_bytes_per_cycle=SURVEY_WORDS[model] * (8 if dtype == "f64" else 4),
+               live=dict(ticks_per_region=k, us_per_tick_back_to_back=median(wall) / k * 1e6, us_per_tick_back_to_back_min=min(wall) / k * 1e6,
+                         us_per_tick_paced=median(wall_paced) / min(k, 2000) * 1e6, ticks_served=served,
+                         note="algorithmic HBM bytes per tick in this mode are the measurements only (the state never leaves the registers): "
+                              "achieved_gbs / frac below are computed on the per-tick-launch byte count for comparison and are NOT a roofline claim"))
+    res["device_ms_per_launch"] = res["device_ms_per_step"]
+    res["kernels"] = [dict(kernel=kernel_name(b, model) + " (LIVE variant)", model=model, units_per_launch=n_targets,
+                           algorithmic_bytes_per_unit=b.algorithmic_bytes, avg_launch_ms=res["device_ms_per_step"],
+                           achieved_gbs=res["achieved_gbs"], frac=res["achieved_gbs"] / HBM_PEAK_GBS)]
+    mgr.close()
     return res
 
 
@@ -907,7 +969,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="skip the gather report (it runs AFTER the line has been printed when N > 1)")
     ap.add_argument("--gather-deadline", type=float, default=60.0, help="seconds the pose gather may take before the run gives up (exit 3)")
     ap.add_argument("--side-file", default="", help="where everything that is not the line goes (default bench_extra.json next to bench.py)")
-    ap.add_argument("--launch-mode", default="auto", choices=["auto", "python", "sequence", "graph", "fused"],
+    ap.add_argument("--launch-mode", default="auto", choices=["auto", "python", "sequence", "graph", "fused", "live"],
                     help="how the per-tick launches are enqueued (always one kernel launch per batch per tick, except 'fused')")
     ap.add_argument("--dry-run", action="store_true", help="no device work: rank start-up, rendezvous, barriers, timing protocol and "
                     "the JSON line only (value is null); what the CPU tests exercise")
@@ -944,7 +1006,7 @@ def main():
     st_kw = {"stream_ticks": args.stream_ticks} if args.stream_ticks else {}
     if args.workload in MIXED:
         res = run_mixed(te, torch, args.workload, args.steps, args.warmup, dist, rank, world,
-                        launch_mode="auto" if args.launch_mode == "fused" else args.launch_mode, reps=args.reps, **st_kw)
+                        launch_mode="auto" if args.launch_mode in ("fused", "live") else args.launch_mode, reps=args.reps, **st_kw)
         parts, seed = MIXED[args.workload][1], MIXED[args.workload][3]
     else:
         res = run_workload(te, torch, args.workload, args.steps, args.warmup, args.lanes, args.targets or None,
@@ -1027,7 +1089,10 @@ def main():
             elif name in MIXED:
                 small = sum(n for _, n in MIXED[name][1]) <= SMALL
                 r = run_mixed(te, torch, name, 512 if small else args.extra_steps, 64 if small else 8, dist, rank, world,
-                              launch_mode="auto" if args.launch_mode == "fused" else args.launch_mode, reps=3)
+                              launch_mode="auto" if args.launch_mode in ("fused", "live") else args.launch_mode, reps=3)
+            elif name.endswith("_live"):                    # the resident mode of a small batch (never `value`)
+                r = run_workload(te, torch, name[:-len("_live")], args.extra_steps, 64, 0, dist=dist, rank=rank, world=world, launch_mode="live", reps=5)
+                r["name"] = name
             elif name.endswith("_strong"):                  # strong scaling: the workload's targets split over the ranks
                 wl = name[:-len("_strong")]
                 per_rank = WORKLOADS[wl][3] // world
@@ -1047,6 +1112,7 @@ def main():
         tr = [k.get("traffic") for k in r["kernels"]]
         extras.append({k: r[k] for k in ("name", "dtype", "targets_per_gpu", "layout", "kernel", "cycles_per_s", "ms_per_step",
                                         "device_ms_per_step", "achieved_gbs", "algorithmic_bytes_per_cycle", "residency", "launch_mode")}
+                      | ({"live": r["live"]} if "live" in r else {})
                       | {"roofline_frac": r["achieved_gbs"] / HBM_PEAK_GBS, "n_gpus": world,
                          "traffic_per_step": (sum(tr) if all(t is not None for t in tr) else None)})
         torch.cuda.empty_cache()

@@ -241,6 +241,32 @@ int target_batch_step_sequence_ring(target_batch_c* b, long n_ticks, double dt, 
  * combinations whose fused form would spill -- are served tick by tick inside the call: same results, one launch per tick. */
 int target_batch_step_fused(target_batch_c* b, long n_ticks, double dt, const void* meas_dev, long tick_stride, long ld,
                             const unsigned char* has_meas_dev, long has_stride);
+/* RESIDENT ("live") mode for small batches -- a live stream without a dispatch per tick.  A 10^4-target tick is shorter than
+ * the 1.5-2 us a dependent kernel launch costs, so at BASELINE.json configs[1] / configs[2] the per-tick launch IS the tick.
+ * Here ONE launch stays on the device with the batch's state in registers and serves tick after tick as the host posts them:
+ *   ..._live_start   launch.  meas_ring_dev / has_ring_dev: a ring of ring_ticks ticks in device memory, laid out as for
+ *                    target_batch_step_sequence; tick k of the session reads entry (first_entry + k) % ring_ticks, which must
+ *                    hold tick k's measurements BEFORE tick k is posted (written by a copy on another stream, or in advance;
+ *                    the kernel reads them past the caches).  max_ticks bounds the session; idle_limit_s (<= 0: 10 s) is how
+ *                    long a wavefront waits without news before it gives up by itself.
+ *   ..._live_post    n more ticks are in the ring: one store to a host-mapped word the wavefronts poll.  Returns at once.
+ *   ..._live_done    ticks that EVERY wavefront has finished;  ..._live_wait: spin until that reaches `tick` (0) or timeout (1)
+ *   ..._live_stop    finish the posted ticks, write the records back, end the launch; returns the ticks served
+ * Results equal those of single ticks bit for bit.  While a session is open the records in HBM are stale: any other call on
+ * the batch (steps, getters, erase, init) ends the session first.  Needs the automatic layout of the shipped models
+ * (axis-separable, packed groups), one (Q, R) class and a batch small enough to be fully resident: ..._live_capacity targets
+ * (about 5 * 10^5 on an MI355X).  Posting faster than the device serves is fine: a wavefront that is behind catches up
+ * without polling. */
+int target_batch_live_start(target_batch_c* b, double dt, const void* meas_ring_dev, long tick_stride, long ld,
+                            const unsigned char* has_ring_dev, long has_stride, long ring_ticks, long first_entry, long max_ticks,
+                            double idle_limit_s);
+int target_batch_live_post(target_batch_c* b, long n_ticks);
+/* n_ticks doorbells of ONE tick each, back to back (what a caller's loop of ..._live_post(b, 1) does, without its call overhead) */
+int target_batch_live_post_each(target_batch_c* b, long n_ticks);
+long target_batch_live_done(target_batch_c* b);
+int target_batch_live_wait(target_batch_c* b, long tick, double timeout_s);
+long target_batch_live_stop(target_batch_c* b);
+long target_batch_live_capacity(target_batch_c* b);
 /* n_ticks ticks of EVERY batch of the manager in one call (BASELINE.json configs[3]/[4]: several motion
  * models per GPU, optionally with the per-tick sphere query "fused on-GPU").  per_batch[i] describes
  * batch i (target_manager_get_batch order): measurements as for target_batch_step_sequence, plus the

@@ -125,6 +125,14 @@ SIGNATURES = {
     "target_batch_step_sequence_ring": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_int]),
     "target_manager_step_sequence_all": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_long, C.c_int, c_double_p, C.c_double, C.c_int]),
     "target_batch_step_fused": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long]),
+    "target_batch_live_start": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_long,
+                                          C.c_long, C.c_double]),
+    "target_batch_live_post": (C.c_int, [C.c_void_p, C.c_long]),
+    "target_batch_live_post_each": (C.c_int, [C.c_void_p, C.c_long]),
+    "target_batch_live_done": (C.c_long, [C.c_void_p]),
+    "target_batch_live_wait": (C.c_int, [C.c_void_p, C.c_long, C.c_double]),
+    "target_batch_live_stop": (C.c_long, [C.c_void_p]),
+    "target_batch_live_capacity": (C.c_long, [C.c_void_p]),
     "target_batch_get_est_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double]),
     "target_stream_fill_dev": (C.c_int, [C.POINTER(StreamSpec), C.c_long, C.c_long, C.c_long, C.c_int, C.c_void_p, C.c_long, C.c_long,
                                          C.c_void_p, C.c_long, C.c_void_p]),

@@ -169,6 +169,7 @@ StepParams Batch::base_params() const {
 }
 
 Batch::~Batch() {
+  if (live_.active) { try { live_stop(); } catch (...) {} }
   (void)hipStreamSynchronize(stream_);
   drop_graphs();
   if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
@@ -179,6 +180,8 @@ Batch::~Batch() {
   if (h_pin_) (void)hipHostFree(h_pin_);
   if (h_cache_) (void)hipHostFree(h_cache_);
   if (h_done_) (void)hipHostFree(h_done_);
+  if (live_.h_posted) (void)hipHostFree(live_.h_posted);
+  (void)hipFree(live_.d_block);
 }
 
 long Batch::zigzag_min_bytes() {
@@ -541,6 +544,94 @@ void Batch::step_fused(long n_ticks, double dt, const void* meas_base, long tick
   if (meas_base && !has_base) nm_acc_ += n_ticks;
 }
 
+void Batch::live_start(double dt, const void* meas_ring, long tick_stride, long ld, const unsigned char* has_ring, long has_stride,
+                       long ring_ticks, long first_entry, long max_ticks, double idle_limit_s) {
+  touch();   // ends a previous session, runs queued one-target steps
+  if (n_ == 0) throw std::runtime_error("target_estimation_amd: live mode on an empty batch");
+  if (!meas_ring || ring_ticks <= 0 || max_ticks <= 0 || first_entry < 0 || ld < n_ || tick_stride < 7 * ld || (has_ring && has_stride < n_))
+    throw std::invalid_argument("target_estimation_amd: live_start: bad measurement ring");
+  if (max_ticks > 0x7fffffffL) throw std::invalid_argument("target_estimation_amd: live_start: at most 2^31 - 1 ticks per session");
+  if (n_classes_ > 1) throw std::runtime_error("target_estimation_amd: live mode serves batches with one (Q, R) class");
+  const long cap = ops_->live_capacity ? ops_->live_capacity() : 0;
+  if (cap <= 0) throw std::runtime_error("target_estimation_amd: live mode needs the axis-separable layout with packed groups");
+  const long waves = (n_ + ops_->L.tpw - 1) / ops_->L.tpw;
+  if (waves > cap)
+    throw std::runtime_error("target_estimation_amd: live mode: " + std::to_string(n_) + " targets need " + std::to_string(waves) +
+                             " resident wavefronts, the device holds " + std::to_string(cap) + " of this kernel");
+  if (waves + 1 > cap) throw std::runtime_error("target_estimation_amd: live mode: no room for the relay wavefront");
+  if (!live_.h_posted) {
+    char* h = nullptr;
+    TE_HIP_CHECK(hipHostMalloc((void**)&h, 128, hipHostMallocMapped | hipHostMallocCoherent));
+    char* d = nullptr;
+    TE_HIP_CHECK(hipHostGetDevicePointer((void**)&d, h, 0));
+    live_.h_posted = reinterpret_cast<long long*>(h); live_.d_posted = reinterpret_cast<long long*>(d);
+    live_.h_done = reinterpret_cast<int*>(h + 64); live_.d_done = reinterpret_cast<int*>(d + 64);
+  }
+  if (waves > live_.cap_waves) {
+    TE_HIP_CHECK(hipStreamSynchronize(stream_));
+    (void)hipFree(live_.d_block);
+    live_.d_block = nullptr;
+    TE_HIP_CHECK(hipMalloc((void**)&live_.d_block, 64 + sizeof(int) * (size_t)waves));
+    live_.cap_waves = waves;
+  }
+  __atomic_store_n(live_.h_posted, 0LL, __ATOMIC_RELAXED);
+  __atomic_store_n(live_.h_done, 0, __ATOMIC_RELAXED);
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  TE_HIP_CHECK(hipMemsetAsync(live_.d_block, 0, 64 + sizeof(int) * (size_t)waves, stream_));   // mirror + progress: zero before EVERY launch
+  StepParams p = base_params();
+  p.meas = meas_ring; p.meas_ld = ld; p.has_meas = has_ring; p.dt = dt;
+  p.n_ticks = (int)max_ticks; p.tick_stride = tick_stride; p.has_stride = has_stride;
+  p.live_posted = live_.d_posted; p.live_done = live_.d_done;
+  p.live_mirror = reinterpret_cast<long long*>(live_.d_block); p.live_progress = reinterpret_cast<int*>(live_.d_block + 64);
+  p.live_ring = ring_ticks; p.live_first = first_entry % ring_ticks;
+  // a poll is a PCIe round trip plus s_sleep: ~1-2 us; the limit is a count of polls
+  const double polls = idle_limit_s > 0 ? idle_limit_s * 5e5 : 5e6;
+  p.live_spin_limit = (unsigned)std::min(polls, 4.0e9);
+  { const char* e = std::getenv("TE_LIVE_FLAGS"); p.live_flags = e ? std::atoi(e) : 0; }
+  ops_->step(p, stream_);   // (the measured-pose rows are not kept during a live session: see measured_pose.hpp)
+  TE_HIP_CHECK(hipGetLastError());
+  live_.active = true; live_.waves = waves; live_.posted = 0; live_.max_ticks = max_ticks; live_.dt = dt;
+  live_.all_measured = has_ring == nullptr;
+}
+
+void Batch::live_post(long n_ticks) {
+  if (!live_.active) throw std::runtime_error("target_estimation_amd: live_post without a live session");
+  if (n_ticks <= 0) return;
+  if (live_.posted + n_ticks > live_.max_ticks) throw std::runtime_error("target_estimation_amd: live_post beyond the session's max_ticks");
+  live_.posted += n_ticks;
+  __atomic_store_n(live_.h_posted, (long long)live_.posted, __ATOMIC_RELEASE);   // the ring entries were written before this call
+}
+
+long Batch::live_done() const {
+  if (!live_.active) return 0;
+  return (long)__atomic_load_n(live_.h_done, __ATOMIC_ACQUIRE);
+}
+
+bool Batch::live_wait(long tick, double timeout_s) const {
+  const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s);
+  for (unsigned spins = 0;; ++spins) {
+    if (live_done() >= tick) return true;
+    __builtin_ia32_pause();
+    if ((spins & 255u) == 255u && std::chrono::steady_clock::now() >= t_end) return false;
+  }
+}
+
+long Batch::live_stop() {
+  if (!live_.active) return 0;
+  __atomic_store_n(live_.h_posted, (long long)live_.posted | kLiveStop, __ATOMIC_RELEASE);
+  live_.active = false;     // whatever happens below, the session is over (flush() must not come back here)
+  TE_HIP_CHECK(hipStreamSynchronize(stream_));   // bounded: every wavefront drains the posted ticks, then sees the stop bit
+  // the relay's last word: the ticks EVERY wavefront served.  The host's stop, or the relay's own after a silent host, reaches
+  // all workers through one device word, so they all stop at the same tick.
+  const long mn = (long)__atomic_load_n(live_.h_done, __ATOMIC_ACQUIRE);
+  t_acc_ += live_.dt * (double)mn;
+  if (live_.all_measured) nm_acc_ += mn;
+  if (mn != live_.posted)
+    throw std::runtime_error("target_estimation_amd: live session ended after " + std::to_string(mn) + " of " + std::to_string(live_.posted) +
+                             " posted ticks (the idle limit stopped it before the last post?)");
+  return (long)mn;
+}
+
 void Batch::step_indexed(const int* slots, long n, double dt, const double* meas_aos, const unsigned char* has) {
   touch();
   if (n <= 0) return;
@@ -654,6 +745,7 @@ static bool spin_wait_enabled() {
 }
 
 void Batch::flush() {
+  if (live_.active) live_stop();   // the records in HBM are stale while a live kernel holds the state
   const long k = (long)pending_.size();
   if (!k) return;
   pin_reserve(k);

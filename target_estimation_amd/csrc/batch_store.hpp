@@ -75,6 +75,27 @@ class Batch {
   // ("effective", temporally fused) cost model -- for replaying recorded streams.
   void step_fused(long n_ticks, double dt, const void* meas_base, long tick_stride, long ld,
                   const unsigned char* has_base, long has_stride);
+  // RESIDENT ("live") mode for small batches: ONE launch stays on the device with the batch's state in registers and serves
+  // tick after tick as the host posts them -- no per-tick dispatch (a dependent launch costs 1.5-2 us, more than the tick of a
+  // 10^4-target batch itself).  Protocol:
+  //   live_start(dt, ring...)   launch; the ring (device memory, SoA ticks as for step_sequence) receives tick k's measurements
+  //                             in entry (first_entry + k) % ring_ticks BEFORE tick k is posted
+  //   live_post(n)              "n more ticks are in the ring": one store to a host-mapped word the wavefronts poll
+  //   live_done()               ticks every wavefront has finished (one host-mapped word, kept by the kernel's relay wavefront)
+  //   live_wait(tick, timeout)  spin until live_done() >= tick
+  //   live_stop()               ask the kernel to finish the posted ticks, store the records and exit; accounts the ticks
+  // Results are those of single ticks, bit for bit.  While a session is open the records in HBM are stale; every other call
+  // on the batch (steps, getters, erase, ...) ends the session first.  The whole grid must be resident (the wavefronts wait
+  // for the host, not for each other, but one that never starts would miss its ticks): refused beyond live_capacity().
+  // A wavefront that sees no news for idle_limit_s gives up on its own (a dead host leaves no kernel behind).
+  void live_start(double dt, const void* meas_ring, long tick_stride, long ld, const unsigned char* has_ring, long has_stride,
+                  long ring_ticks, long first_entry, long max_ticks, double idle_limit_s);
+  void live_post(long n_ticks);
+  long live_done() const;
+  bool live_wait(long tick, double timeout_s) const;
+  long live_stop();            // returns the ticks served
+  bool live_active() const { return live_.active; }
+  long live_capacity_targets() const { return ops_->live_capacity ? ops_->live_capacity() * ops_->L.tpw : 0; }
   // One tick over the listed slots, host inputs (meas rows follow the order of `slots`).
   void step_indexed(const int* slots, long n, double dt, const double* meas_aos, const unsigned char* has);
   // The same with everything already on the device: idx_dev [n] = slot of entry e or a negative number (entry skipped);
@@ -266,6 +287,18 @@ class Batch {
   unsigned done_seq_ = 0;
   void wait_done(int seq);                   // spin on *h_done_ == seq, falling back to hipStreamSynchronize
   void touch() { flush(); cache_valid_ = false; }   // call before anything that changes state
+  struct Live {
+    bool active = false;
+    long long* h_posted = nullptr;   // host-mapped: [0] the doorbell (count | stop bit), [8] (as int) the relay's "done" word
+    long long* d_posted = nullptr;   // the same block as the device sees it
+    int* h_done = nullptr;
+    int* d_done = nullptr;
+    char* d_block = nullptr;         // device memory: [mirror word, padded to 64 B][progress words of the wavefronts]
+    long waves = 0, cap_waves = 0;
+    long posted = 0, max_ticks = 0;
+    double dt = 0.0;
+    bool all_measured = false;
+  } live_;
 };
 
 }  // namespace te

@@ -39,6 +39,14 @@ struct StepParams {
   double* o_acc = nullptr;
   int* done_flag = nullptr;
   int done_seq = 0;
+  // resident ("live") launch: live_posted != null (kf_step.hpp StepArgs::live_*); n_ticks = the most ticks it will serve
+  const long long* live_posted = nullptr;
+  long long* live_mirror = nullptr;
+  int* live_progress = nullptr;
+  int* live_done = nullptr;
+  long live_ring = 0, live_first = 0;
+  unsigned live_spin_limit = 0;
+  int live_flags = 0;
 };
 
 struct Ops {
@@ -46,6 +54,8 @@ struct Ops {
   int wpb;  // wavefronts per workgroup of the step kernel
   bool fused_query;  // step() honours StepParams::q_delta
   void (*step)(const StepParams&, hipStream_t);
+  // wavefronts of the live kernel the device can hold at once (0: this (model, precision, layout) has no live kernel)
+  long (*live_capacity)();
   void (*init)(const InitArgs&, hipStream_t);
   void (*get_state)(char* rec, const int* idx, long n, double* x, double* P, hipStream_t);
   void (*set_state)(char* rec, const int* idx, long n, const double* x, const double* P, const double* uw, hipStream_t);

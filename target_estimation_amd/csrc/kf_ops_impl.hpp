@@ -15,6 +15,20 @@ template <class M, typename T, int G, int LAYOUT = LAYOUT_FULL>
 struct OpsImpl {
   using C = Cfg<M, T, G, LAYOUT>;
 
+  static constexpr bool kHasLive = LAYOUT == LAYOUT_SEPARABLE_PACKED;
+  static long live_capacity() {
+    if constexpr (kHasLive) {
+      int per_cu = 0, dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kf_step_sep_kernel<M, T, LAYOUT, false, true, false, false, true>, 64, 0) != hipSuccess)
+        return 0;
+      // the occupancy query can over-report by one block per CU (cdna_hip_programming.md, residency): keep one in hand
+      return (long)(per_cu > 1 ? per_cu - 1 : 1) * (long)prop.multiProcessorCount;
+    } else {
+      return 0;
+    }
+  }
   static void step(const StepParams& p, hipStream_t s) {
     if (p.n <= 0) return;
     StepArgs<T> a;
@@ -26,6 +40,21 @@ struct OpsImpl {
     a.q_radius = p.q_radius; a.q_delta = p.q_delta; a.q_pose = p.q_pose;
     a.reverse = p.reverse;
     a.o_pose = p.o_pose; a.o_twist = p.o_twist; a.o_acc = p.o_acc; a.done_flag = p.done_flag; a.done_seq = p.done_seq;
+    a.live_posted = p.live_posted; a.live_mirror = p.live_mirror; a.live_progress = p.live_progress; a.live_done = p.live_done;
+    a.live_ring = p.live_ring; a.live_first = p.live_first;
+    a.live_spin_limit = p.live_spin_limit; a.live_flags = p.live_flags;
+    if (p.live_posted) {   // resident launch: one wavefront per workgroup, every workgroup resident (Batch::live_start checked the capacity)
+      if constexpr (kHasLive) {
+        if (p.idx || p.cls || p.q_delta || p.rec_out || !p.live_progress || !p.live_mirror || !p.live_done || p.live_ring <= 0 || p.n_ticks < 1)
+          throw std::runtime_error("target_estimation_amd: a live launch is a dense launch of a one-class batch over a measurement ring");
+        const long waves_live = (p.n + C::TPW - 1) / C::TPW;
+        // + 1: the relay wavefront (kf_step.hpp live_relay)
+        hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, false, true, false, false, true>), dim3((unsigned)waves_live + 1), dim3(64), 0, s, a);
+        return;
+      } else {
+        throw std::runtime_error("target_estimation_amd: live mode needs the axis-separable layout with packed groups (the automatic choice for the shipped models)");
+      }
+    }
     if (p.o_pose && (!p.idx || p.n > C::TPW || !p.o_twist || !p.o_acc || !p.done_flag))
       throw std::runtime_error("target_estimation_amd: the fused getter table needs an indexed launch of at most one wavefront of entries");
     static const int nt_env = [] { const char* e = std::getenv("TE_NT_MEAS"); return e ? std::atoi(e) : -1; }();
@@ -133,7 +162,7 @@ struct OpsImpl {
   static const Ops* get() {
     static const Ops ops = {
         LayoutInfo{C::N, C::K, G, LAYOUT, C::TPW, C::LPT, C::RW, C::TILE_BYTES, C::TILE_PAYLOAD},
-        C::WPB, true, &step, &init, &get_state, &set_state, &move_record, &move_records, &outputs, &pack_meas, &intersect};
+        C::WPB, true, &step, &live_capacity, &init, &get_state, &set_state, &move_record, &move_records, &outputs, &pack_meas, &intersect};
     return &ops;
   }
 };

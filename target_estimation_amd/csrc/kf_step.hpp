@@ -79,7 +79,104 @@ struct StepArgs {
   double* o_acc;
   int* done_flag;
   int done_seq;
+  // RESIDENT ("live") launches of small batches (LIVE variants of the separable kernel; Batch::live_start): the state stays in
+  // registers while the kernel waits, tick after tick, for the host to post that the tick's measurements are in the ring.
+  // Host memory is touched by ONE wavefront only, the RELAY (the extra, last workgroup of the grid): a store from the GPU to
+  // host memory costs 0.6-1.6 us and they serialise (measured: a progress word per worker wavefront per tick made a
+  // 157-wavefront tick 250 us long), so the workers talk to device memory and the relay carries two words over PCIe:
+  //   live_posted   host-mapped, host -> relay: ticks posted so far; sign bit = "stop once they are done"
+  //   live_mirror   device word, relay -> workers: the same value (the relay adds the stop bit itself when the host has
+  //                 been silent for live_spin_limit polls: a dead host leaves no kernel behind, and every worker stops at
+  //                 the same tick)
+  //   live_progress device words [wavefronts], worker -> relay: ticks this wavefront has finished
+  //   live_done     host-mapped, relay -> host: the minimum of live_progress
+  //   live_ring / live_first   the measurement ring holds live_ring ticks; tick k of the session reads entry (live_first + k) % live_ring
+  // n_ticks = the most ticks the launch will serve.
+  const long long* live_posted;
+  long long* live_mirror;
+  int* live_progress;
+  int* live_done;
+  long live_ring;
+  long live_first;
+  unsigned live_spin_limit;
+  int live_flags;   // experiments (TE_LIVE_FLAGS): 2 = plain measurement loads
 };
+
+__device__ __forceinline__ long long wave_uniform_ll(long long v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+// Worker side: wait until tick number `need` (1-based) has been posted.  false: stop requested with nothing more to do (or
+// the backstop limit ran out).  `seen` caches the last value read, so a wavefront that is behind catches up without
+// polling.  ONE lane reads the mirror word (a device-scope atomic load on the vector path: the scalar cache may hold a
+// stale copy; 64 lanes loading one address past the caches would be 64 requests).
+__device__ __forceinline__ bool live_wait_tick(const long long* mirror, long long need, unsigned limit, long long& seen, int lane) {
+  if ((seen & kLiveCount) >= need) return true;
+  for (unsigned spins = 0;; ++spins) {
+    long long v = 0;
+    if (lane == 0) v = __hip_atomic_load(mirror, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    seen = wave_uniform_ll(v);
+    if ((seen & kLiveCount) >= need) return true;
+    if (seen < 0) return false;        // stop, and every posted tick is done
+    if (spins >= limit) return false;  // backstop (the relay stops the session long before)
+    __builtin_amdgcn_s_sleep(4);
+  }
+}
+
+// The relay wavefront: host doorbell -> device mirror, worker progress -> host.  Leaves when a stop was requested (by the
+// host, or by itself after `limit` polls without news from the host) and every worker has served the posted ticks.
+__device__ __forceinline__ void live_relay(const long long* posted, long long* mirror, const int* progress, int* done, long waves,
+                                           unsigned limit, int lane) {
+  long long last = 0;
+  int last_done = 0;
+  unsigned idle = 0, after_stop = 0;
+  for (;;) {
+    long long v = 0;
+    if (lane == 0) v = __hip_atomic_load(posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // one PCIe read per round
+    v = wave_uniform_ll(v);
+    if (last < 0) v = last;                                  // stopping: the host's word no longer matters
+    else if (idle >= limit) v = last | kLiveStop;            // a silent host: stop the session at what was posted
+    if (v != last) {
+      if (lane == 0) __hip_atomic_store(mirror, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = v;
+      idle = 0;
+    } else {
+      ++idle;
+    }
+    int mn = 0x7fffffff;
+    for (long w = lane; w < waves; w += 64) {
+      const int p = __hip_atomic_load(&progress[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      mn = p < mn ? p : mn;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const int o = __shfl_xor(mn, off, 64);
+      mn = o < mn ? o : mn;
+    }
+    if (mn != last_done) {
+      if (lane == 0) __hip_atomic_store(done, mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // one PCIe write per change
+      last_done = mn;
+    }
+    if (last < 0) {
+      if ((long long)mn >= (last & kLiveCount)) break;       // every worker has served the posted ticks and is leaving
+      if (++after_stop >= limit) break;                      // (a worker that never ran: nothing more to wait for)
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+// measurement word of a live tick: written by a copy engine or the host while the kernel runs, so it is read past the caches
+template <typename T> __device__ __forceinline__ T load_meas_live(const T* p);
+template <> __device__ __forceinline__ double load_meas_live<double>(const double* p) {
+  const unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return __longlong_as_double((long long)b);
+}
+template <> __device__ __forceinline__ float load_meas_live<float>(const float* p) {
+  const unsigned b = __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return __uint_as_float(b);
+}
 
 template <typename T> __device__ __forceinline__ T load_meas(const T* p, int nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
 

@@ -86,10 +86,13 @@ __device__ __forceinline__ void sep_linear_axis(T* x, T (&P)[NB][NB], const T (&
 template <class M, typename T, int LAYOUT, bool PERQR>
 constexpr int sep_min_waves() { return (PERQR && M::TYPE == ANGULAR_RATES && sizeof(T) == 8 && LAYOUT == LAYOUT_SEPARABLE_PACKED) ? 3 : 1; }
 
-template <class M, typename T, int LAYOUT, bool INDEXED, bool FUSED = false, bool QUERY = false, bool PERQR = false>
+// LIVE: a resident launch (StepArgs::live_*): the tick loop of FUSED with a wait for the host's doorbell in front of every tick
+// and a progress word behind it.  Same arithmetic per tick, same results as single ticks.
+template <class M, typename T, int LAYOUT, bool INDEXED, bool FUSED = false, bool QUERY = false, bool PERQR = false, bool LIVE = false>
 __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR>())) kf_step_sep_kernel(const StepArgs<T> a) {
   static_assert(!(QUERY && (INDEXED || FUSED)), "the fused query is for dense single-tick launches");
   static_assert(!(PERQR && (FUSED || QUERY)), "per-class Q/R: single-tick launches without the fused query");
+  static_assert(!LIVE || (FUSED && !INDEXED && !QUERY && !PERQR), "live launches are dense multi-tick launches");
   using C = Cfg<M, T, 1, LAYOUT>;
   static_assert(C::SEP, "separable layouts only");
   constexpr int N = C::N, K = C::K, NB = C::NB, TPW = C::TPW;
@@ -97,7 +100,15 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR>())) k
 
   const int lane = threadIdx.x & 63;
   long wg = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if constexpr (LIVE) {   // the workgroup behind the last worker is the relay between the host's words and the device's
+    const long workers = (a.n + TPW - 1) / TPW;
+    if (wg == workers) {
+      live_relay(a.live_posted, a.live_mirror, a.live_progress, a.live_done, workers, a.live_spin_limit, lane);
+      return;
+    }
+  }
   if (wg * TPW >= a.n) return;
+  const long wave_id = wg;                               // LIVE: index of this wavefront's progress word
   if (a.reverse) wg = (a.n + TPW - 1) / TPW - 1 - wg;   // zig-zag traversal (StepArgs::reverse)
   const long entry = wg * TPW + lane;
   bool valid = entry < a.n;
@@ -182,9 +193,15 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR>())) k
   }
   int n_has = 0;
   const int n_ticks = FUSED ? a.n_ticks : 1;
+  long long live_seen = 0;
   for (int tick = 0; tick < n_ticks; ++tick) {
-  const T* meas_t = a.meas ? a.meas + (long)tick * a.tick_stride : nullptr;
-  const unsigned char* has_t = a.has_meas ? a.has_meas + (long)tick * a.has_stride : nullptr;
+  long slot_tick = tick;
+  if constexpr (LIVE) {
+    if (!live_wait_tick(a.live_mirror, (long long)tick + 1, 2u * a.live_spin_limit + 1000000u, live_seen, lane)) break;
+    slot_tick = (a.live_first + tick) % a.live_ring;
+  }
+  const T* meas_t = a.meas ? a.meas + slot_tick * a.tick_stride : nullptr;
+  const unsigned char* has_t = a.has_meas ? a.has_meas + slot_tick * a.has_stride : nullptr;
   // Every measurement word of the tick is requested up front, right behind the record loads and regardless
   // of the mask: with a cache-resident state they are the only operands that come from HBM itself, and one
   // round trip for all of them replaces one per axis.
@@ -195,8 +212,14 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR>())) k
   unsigned char hmask = 1;
   if (valid && meas_t != nullptr) {
 #pragma unroll
-    for (int c = 0; c < MW; ++c) ymeas[c] = load_meas(&meas_t[(long)c * a.meas_ld + entry], a.nt_meas);
-    if (has_t != nullptr) hmask = has_t[entry];
+    for (int c = 0; c < MW; ++c) {
+      if constexpr (LIVE) ymeas[c] = (a.live_flags & 2) ? meas_t[(long)c * a.meas_ld + entry] : load_meas_live(&meas_t[(long)c * a.meas_ld + entry]);
+      else ymeas[c] = load_meas(&meas_t[(long)c * a.meas_ld + entry], a.nt_meas);
+    }
+    if (has_t != nullptr) {
+      if constexpr (LIVE) hmask = (unsigned char)__hip_atomic_load(&has_t[entry], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      else hmask = has_t[entry];
+    }
   }
   const bool has = valid && meas_t != nullptr && hmask != 0;
   n_has += has ? 1 : 0;
@@ -463,6 +486,9 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR>())) k
     }
   }
 
+  if constexpr (LIVE) {   // tick `tick` is done (state in registers): a word in device memory for the relay
+    if (lane == 0) __hip_atomic_store(&a.live_progress[wave_id], tick + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   }  // tick loop
   if (valid) {
     if constexpr (!INDEXED) {

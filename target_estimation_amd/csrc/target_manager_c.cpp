@@ -416,6 +416,35 @@ int target_batch_step_fused(target_batch_c* b, long n_ticks, double dt, const vo
   });
 }
 
+// ---- resident ("live") mode
+int target_batch_live_start(target_batch_c* b, double dt, const void* meas_ring_dev, long tick_stride, long ld,
+                            const unsigned char* has_ring_dev, long has_stride, long ring_ticks, long first_entry, long max_ticks,
+                            double idle_limit_s) {
+  return guarded("target_batch_live_start", [&] { BatchLock lk(B(b));
+    B(b)->live_start(dt, meas_ring_dev, tick_stride, ld, has_ring_dev, has_stride, ring_ticks, first_entry, max_ticks, idle_limit_s);
+  });
+}
+int target_batch_live_post(target_batch_c* b, long n_ticks) {
+  return guarded("target_batch_live_post", [&] { BatchLock lk(B(b)); B(b)->live_post(n_ticks); });
+}
+int target_batch_live_post_each(target_batch_c* b, long n_ticks) {
+  return guarded("target_batch_live_post_each", [&] { BatchLock lk(B(b)); for (long i = 0; i < n_ticks; ++i) B(b)->live_post(1); });
+}
+long target_batch_live_done(target_batch_c* b) {
+  return guarded_value<long>("target_batch_live_done", -1L, [&] { return B(b)->live_done(); });   // reads host-mapped words: no lock
+}
+int target_batch_live_wait(target_batch_c* b, long tick, double timeout_s) {
+  int late = 0;
+  const int rc = guarded("target_batch_live_wait", [&] { late = B(b)->live_wait(tick, timeout_s) ? 0 : 1; });
+  return rc != 0 ? rc : late;
+}
+long target_batch_live_stop(target_batch_c* b) {
+  return guarded_value<long>("target_batch_live_stop", -1L, [&] { BatchLock lk(B(b)); return B(b)->live_stop(); });
+}
+long target_batch_live_capacity(target_batch_c* b) {
+  return guarded_value<long>("target_batch_live_capacity", -1L, [&] { return B(b)->live_capacity_targets(); });
+}
+
 int target_batch_get_est_dev(target_batch_c* b, double* pose_dev, double* twist_dev, double* acc_dev, int at_time, double t1) {
   return guarded("target_batch_get_est_dev", [&] { BatchLock lk(B(b)); B(b)->outputs_dev(pose_dev, twist_dev, acc_dev, at_time != 0, t1); });
 }

@@ -211,6 +211,10 @@ __host__ __device__ inline long record_word_offset(int lane, int w) {
   return C::TAIL1_OFF + (long)lane * (long)sizeof(T);
 }
 
+// the doorbell word of a resident ("live") launch (kf_step.hpp StepArgs::live_posted): ticks posted | stop bit
+constexpr long long kLiveStop = (long long)(1ull << 63);    // sign bit: "stop once the posted ticks are done"
+constexpr long long kLiveCount = (long long)(~(1ull << 63));
+
 struct LayoutInfo {
   int n, m, g, layout, tpw, lpt, record_words;
   long tile_bytes, tile_payload;

@@ -126,6 +126,36 @@ class Batch:
         _check(self._lib.target_batch_step_fused(self._h, meas.shape[0], float(dt), meas.data_ptr(), meas.stride(0),
                                                   meas.stride(1), hp, hs), "target_batch_step_fused")
 
+    # ---- resident ("live") mode: one launch serves tick after tick as the host posts them (target_batch_c.h)
+    def live_start(self, dt, meas_ring, has_ring=None, first_entry=0, max_ticks=1 << 30, idle_limit_s=10.0):
+        """meas_ring: CUDA tensor [ring_ticks, 7, ld] in the batch precision; has_ring: CUDA uint8 [ring_ticks, >= size] or None."""
+        assert meas_ring.is_cuda and meas_ring.dim() == 3 and meas_ring.shape[1] == 7 and meas_ring.stride(2) == 1
+        assert meas_ring.dtype == self.torch_dtype() and meas_ring.shape[2] >= self.size
+        hp, hs = None, 0
+        if has_ring is not None:
+            assert has_ring.is_cuda and has_ring.dim() == 2 and has_ring.element_size() == 1 and has_ring.shape[0] == meas_ring.shape[0]
+            hp, hs = has_ring.data_ptr(), has_ring.stride(0)
+        _check(self._lib.target_batch_live_start(self._h, float(dt), meas_ring.data_ptr(), meas_ring.stride(0), meas_ring.stride(1), hp, hs,
+                                                 meas_ring.shape[0], int(first_entry), int(max_ticks), float(idle_limit_s)), "target_batch_live_start")
+
+    def live_post(self, n_ticks=1):
+        _check(self._lib.target_batch_live_post(self._h, int(n_ticks)), "target_batch_live_post")
+
+    def live_post_each(self, n_ticks):
+        _check(self._lib.target_batch_live_post_each(self._h, int(n_ticks)), "target_batch_live_post_each")
+
+    def live_done(self):
+        return self._lib.target_batch_live_done(self._h)
+
+    def live_wait(self, tick, timeout_s=5.0):
+        rc = _check(self._lib.target_batch_live_wait(self._h, int(tick), float(timeout_s)), "target_batch_live_wait")
+        return rc == 0
+
+    def live_stop(self):
+        return _check(self._lib.target_batch_live_stop(self._h), "target_batch_live_stop")
+
+    live_capacity = property(lambda s: s._lib.target_batch_live_capacity(s._h))
+
     def get_est(self, pose=True, twist=True, acc=True, t1=None):
         """Derived outputs of every slot as CUDA double tensors ([size,7], [size,6], [size,6])."""
         import torch

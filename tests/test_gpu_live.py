@@ -1,0 +1,178 @@
+"""Resident ("live") mode (target_batch_live_*): ONE launch holds a small batch's state in registers and serves tick after tick
+as the host posts them -- BASELINE.json configs[1] / configs[2] are launch-bound, a dependent launch costs more than their
+tick.  Results must be those of single ticks bit for bit, and the oracle's within the usual tolerance.  What the session
+replaces: the caller's per-tick loop over targets, src/target_manager.cpp:190-225 / src/target_node.cpp:36-44.
+
+Every test drives the manager on its own NON-blocking stream and refills the ring on another one: work queued behind the
+resident kernel on its stream (or on the legacy default stream) would wait for the session to end."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import model_path
+from test_gpu_parity import check_state
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+te = pytest.importorskip("target_estimation_amd")
+
+MODELS = {"angular_rates": 0, "angular_velocities": 1, "uniform_acceleration": 2, "uniform_velocity": 3}
+
+
+def _setup(models, name, dtype, N, ticks, dt, seed, availability=1.0):
+    from target_estimation_amd.streams import make_stream
+    live = torch.cuda.Stream()
+    st = make_stream(MODELS[name], N, ticks, dt, seed, dtype=dtype, availability=availability)
+    torch.cuda.synchronize()
+    mgr = te.TargetManager(model_path(name), dtype=dtype)
+    mgr.set_stream(live.cuda_stream)
+    ids = np.arange(N, dtype=np.uint32) + 3
+    p0 = st["p0"].cpu().numpy()
+    mgr.init_batch(ids, dt, 0.0, p0)
+    mgr.synchronize()
+    return mgr, mgr.batches()[0], st, ids, p0, live
+
+
+@pytest.mark.parametrize("name,dtype,N", [("uniform_velocity", "f64", 10_000), ("uniform_acceleration", "f32", 100_000),
+                                          ("angular_rates", "f64", 3_000), ("angular_velocities", "f32", 5_001)])
+def test_live_session_equals_single_ticks_bit_for_bit(models, name, dtype, N):
+    """configs[1] / configs[2] sizes among them.  40 ticks through a ring of 16 that the host refills on a second stream while
+    the session runs; the ticks posted one doorbell at a time, in bursts, and all at once; against the same ticks as single
+    launches (bit for bit) and against the oracle on a sample."""
+    ticks, ring, dt = 40, 16, 0.004
+    m = models[name]
+    mgr, b, st, ids, p0, live = _setup(models, name, dtype, N, ticks, dt, 91, availability=0.9)
+    meas, has = st["meas"], st["has_meas"]
+    # reference: single ticks on a second manager
+    ref = te.TargetManager(model_path(name), dtype=dtype)
+    ref.init_batch(ids, dt, 0.0, p0)
+    rb = ref.batches()[0]
+    for s in range(ticks):
+        rb.step(dt, meas[s], has[s])
+    want = ref.get_state_batch(ids)
+    want_nm = [ref.getNumberMeasurements(int(i)) for i in ids[:50]]
+    torch.cuda.synchronize()
+    assert b.live_capacity >= N
+    ring_m, ring_h = meas[:ring].clone(), has[:ring].clone()
+    torch.cuda.synchronize()
+    copy = torch.cuda.Stream()
+    b.live_start(dt, ring_m, ring_h, max_ticks=ticks, idle_limit_s=3.0)
+    b.live_post(1)                                   # one doorbell, one tick
+    assert b.live_wait(1, 5.0) and b.live_done() >= 1
+    b.live_post_each(ring - 1)                       # the rest of the ring, a doorbell per tick, back to back
+    assert b.live_wait(ring, 5.0)
+    done = ring
+    while done < ticks:                              # refill the whole ring behind the session, post it as ONE doorbell
+        k = min(ring, ticks - done)
+        with torch.cuda.stream(copy):
+            ring_m[:k].copy_(meas[done:done + k])
+            ring_h[:k].copy_(has[done:done + k])
+        copy.synchronize()
+        b.live_post(k)
+        done += k
+        assert b.live_wait(done, 5.0)
+    assert b.live_stop() == ticks
+    got = mgr.get_state_batch(ids)
+    np.testing.assert_array_equal(got[0], want[0])
+    np.testing.assert_array_equal(got[1], want[1])
+    assert [mgr.getNumberMeasurements(int(i)) for i in ids[:50]] == want_nm
+    assert mgr.getTime(int(ids[0])) == pytest.approx(ticks * dt, abs=1e-12)
+    sample = np.arange(0, N, max(1, N // 300))
+    refs = oracle.stream_sample(m["model"], 91, sample, ticks, dt, availability=0.9, dtype=dtype)
+    orc = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], p0[sample], dt, dtype=dtype)
+    for s in range(ticks):
+        orc.step(dt, refs["meas"][s], refs["has_meas"][s])
+    check_state(mgr, ids[sample], orc, dtype, "%s after a live session" % name)
+    ref.close(); mgr.close()
+
+
+def test_any_other_call_ends_the_session_first(models):
+    """While a session is open the records in HBM are stale: getters, steps, erase and init end it first (and see its ticks)."""
+    name, dtype, N, dt = "uniform_acceleration", "f64", 2000, 0.004
+    mgr, b, st, ids, p0, live = _setup(models, name, dtype, N, 12, dt, 5)
+    meas = st["meas"]
+    ref = te.TargetManager(model_path(name), dtype=dtype)
+    ref.init_batch(ids, dt, 0.0, p0)
+    rb = ref.batches()[0]
+    b.live_start(dt, meas, max_ticks=100, idle_limit_s=3.0)
+    b.live_post(5)
+    pose = mgr.getTargetPose(int(ids[7]))[1]              # a getter: stops the session after its 5 ticks
+    for s in range(5):
+        rb.step(dt, meas[s])
+    np.testing.assert_array_equal(pose, ref.getTargetPose(int(ids[7]))[1])
+    assert b.live_done() == 0 and b.live_stop() == 0      # no session any more
+    with pytest.raises(RuntimeError, match="without a live session"):
+        b.live_post(1)
+    b.live_start(dt, meas, first_entry=5, max_ticks=100, idle_limit_s=3.0)   # a second session continues with ring entry 5
+    b.live_post(3)
+    mgr.update(int(ids[0]), dt, p0[0])                    # queued one-target step ...
+    assert mgr.erase(int(ids[1]))                         # ... and an erase: the session ends, then both run
+    for s in range(5, 8):
+        rb.step(dt, meas[s])
+    ref.update(int(ids[0]), dt, p0[0])
+    assert ref.erase(int(ids[1]))
+    keep = np.delete(ids, 1)
+    got, want = mgr.get_state_batch(keep), ref.get_state_batch(keep)
+    np.testing.assert_array_equal(got[0], want[0])
+    np.testing.assert_array_equal(got[1], want[1])
+    ref.close(); mgr.close()
+
+
+def test_live_mode_refuses_what_it_cannot_serve(models):
+    name, dt = "uniform_velocity", 0.004
+    m = models[name]
+    live = torch.cuda.Stream()
+    ring = torch.zeros((4, 7, 64), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    mgr = te.TargetManager(dtype="f64")
+    mgr.set_stream(live.cuda_stream)
+    rng = np.random.default_rng(0)
+    B = rng.normal(size=(6, 6)) * 0.1
+    Qc = m["Q"] + (B @ B.T) * 1e-6                        # coupled Q: the dense kernel's layout, no live kernel
+    ids = np.arange(10, dtype=np.uint32)
+    p0 = np.tile([0, 0, 0, 0, 0, 0, 1.0], (10, 1))
+    mgr.init_batch(ids, dt, 0.0, p0, type=m["model"], Q=Qc, R=m["R"], P0=m["P"])
+    b = mgr.batches()[0]
+    assert b.live_capacity == 0
+    with pytest.raises(RuntimeError, match="axis-separable"):
+        b.live_start(dt, ring)
+    mgr.close()
+    mgr = te.TargetManager(model_path(name))
+    mgr.set_stream(live.cuda_stream)
+    mgr.init_batch(ids, dt, 0.0, p0)
+    mgr.init_batch(ids + 100, dt, 0.0, p0, type=m["model"], Q=m["Q"] * 2, R=m["R"], P0=m["P"])   # a second (Q, R) class
+    b = mgr.batches()[0]
+    assert b.num_classes == 2
+    with pytest.raises(RuntimeError, match="one \\(Q, R\\) class"):
+        b.live_start(dt, ring)
+    mgr.close()
+    mgr = te.TargetManager(model_path(name))
+    mgr.set_stream(live.cuda_stream)
+    mgr.init_batch(ids, dt, 0.0, p0)
+    b = mgr.batches()[0]
+    with pytest.raises(RuntimeError, match="bad measurement ring"):
+        b._lib.target_batch_live_start(b._h, dt, ring.data_ptr(), 7 * 64, 4, None, 0, 4, 0, 10, 1.0) and None
+        raise RuntimeError(te.capi.last_error())
+    b.live_start(dt, ring, max_ticks=3, idle_limit_s=3.0)
+    b.live_post(3)
+    with pytest.raises(RuntimeError, match="beyond the session"):
+        b.live_post(1)
+    assert b.live_wait(3, 5.0) and b.live_stop() == 3
+    mgr.close()
+
+
+def test_an_abandoned_session_ends_by_itself(models):
+    """A host that stops posting (or dies) must not leave a kernel behind: after idle_limit_s without news every wavefront
+    stores its records and exits; stop() then finds an even, complete session."""
+    import time
+    mgr, b, st, ids, p0, live = _setup(models, "uniform_velocity", "f64", 5000, 4, 0.004, 8)
+    b.live_start(0.004, st["meas"], max_ticks=100, idle_limit_s=0.5)
+    b.live_post(2)
+    assert b.live_wait(2, 5.0)
+    t0 = time.time()
+    live.synchronize()                                    # returns once the kernel has given up
+    assert time.time() - t0 < 8.0
+    assert b.live_stop() == 2
+    x, P = mgr.get_state_batch(ids[:10])
+    assert np.isfinite(x).all() and np.isfinite(P).all()
+    mgr.close()
