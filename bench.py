@@ -126,7 +126,7 @@ MIXED = {
 }
 HEADLINE = "cfg4_1gpu"
 
-DEFAULT_EXTRA = ("cfg2,cfg2_live,cfg2_stream,cfg3,cfg3_live,cfg3_stream,cfg4,cfg4_64,cfg5,cfg4_1gpu32,cfg5_1gpu,cfg5_1gpu64,"
+DEFAULT_EXTRA = ("cfg2,cfg2_live,cfg2_stream,cfg3,cfg3_live,cfg3_stream,cfg4,cfg4_live,cfg4_64,cfg5,cfg4_1gpu32,cfg5_1gpu,cfg5_1gpu64,"
                  "uv1m,uv1m32,ua1m64,ua1m,av1m64,av1m,ar1m64,ar1m,"
                  "uv10m,ua10m,av4m64,ar4m64,av8m,ar8m,cfg4_4m,"
                  "ar1m_a90,av1m_a90,ar1m64_1kcls,ar1m64_1kcls_rand,ar100k64_1kcls,uv1m_1kcls,uv1m_full,uv1m_packed,ar1m_full,ar1m_packed,av1m_packed,ar1m64_full,av1m64_full,ar1m64_packed,av1m64_packed")
@@ -360,9 +360,7 @@ def run_live(te, torch, name, desc, model, dtype, mgr, b, meas, has, ids, dt, n_
     device-wide synchronise would wait for the session."""
     import numpy as np
     torch.cuda.synchronize()
-    side = torch.cuda.Stream()
-    mgr.set_stream(side.cuda_stream)     # a non-blocking stream of its own: nothing else may queue behind the resident kernel
-    b.live_start(dt, meas, has, max_ticks=1 << 30, idle_limit_s=10.0)
+    b.live_start(dt, meas, has, max_ticks=1 << 30, idle_limit_s=10.0)   # (the resident kernel runs on a stream of its own)
     posted = [0]
 
     def back_to_back(count):
@@ -409,6 +407,56 @@ def run_live(te, torch, name, desc, model, dtype, mgr, b, meas, has, ids, dt, n_
     return res
 
 
+def run_live_mixed(te, torch, name, desc, parts, dtype, mgr, batches, meas, dt, n_all, world, steps, warmup, reps, ring_ticks):
+    """run_live for every batch of a manager at once (target_manager_live_*_all): one resident kernel per motion model."""
+    torch.cuda.synchronize()
+    mgr.live_start_all(dt, meas, max_ticks=1 << 30, idle_limit_s=10.0)
+    posted = [0]
+
+    def back_to_back(count):
+        mgr.live_post_all(count, one_doorbell_per_tick=True)
+        posted[0] += count
+        if not mgr.live_wait_all(posted[0], 20.0):
+            raise RuntimeError("live sessions stalled at %d of %d" % (mgr.live_done_all(), posted[0]))
+
+    def paced(count):
+        for _ in range(count):
+            mgr.live_post_all(1)
+            posted[0] += 1
+            if not mgr.live_wait_all(posted[0], 20.0):
+                raise RuntimeError("live sessions stalled")
+
+    def timed(fn, k, r):
+        out = []
+        for _ in range(r):
+            t0 = time.perf_counter()
+            fn(k)
+            out.append(time.perf_counter() - t0)
+        return out
+    back_to_back(max(warmup, 64))
+    k = max(steps, 4096)
+    wall = timed(back_to_back, k, max(reps, 5))
+    wall_paced = timed(paced, min(k, 2000), 3)
+    served = mgr.live_stop_all()
+    assert served == posted[0]
+    for b in batches:
+        p, _, _ = b.get_est(twist=False, acc=False)
+        assert torch.isfinite(p).all()
+    models = [m for m, _ in parts]
+    kernels = [kernel_name(b, m) + " (LIVE variant)" for b, m in zip(batches, models)]
+    res = summarize(name, desc, models, dtype, batches, kernels, n_all, world, k, wall, [w * 1e3 for w in wall],
+                    "live: one resident launch per motion model, one tick per doorbell, back to back")
+    res.update(measurement_ring_ticks=ring_ticks, measurement_ring_bytes=int(sum(m.numel() * m.element_size() for m in meas)),
+               live=dict(ticks_per_region=k, us_per_tick_back_to_back=median(wall) / k * 1e6, us_per_tick_back_to_back_min=min(wall) / k * 1e6,
+                         us_per_tick_paced=median(wall_paced) / min(k, 2000) * 1e6, ticks_served=served,
+                         note="the state never leaves the registers: achieved_gbs / frac are on the per-tick-launch byte count, for comparison only"))
+    res["kernels"] = [dict(kernel=kn, model=m, units_per_launch=b.size, algorithmic_bytes_per_unit=b.algorithmic_bytes,
+                           avg_launch_ms=res["device_ms_per_step"], achieved_gbs=res["achieved_gbs"], frac=res["achieved_gbs"] / HBM_PEAK_GBS)
+                      for kn, m, b in zip(kernels, models, batches)]
+    mgr.close()
+    return res
+
+
 def run_mixed(te, torch, name, steps, warmup, dist=None, rank=0, world=1, stream_ticks=64, launch_mode="auto", reps=3):
     """Several motion models (batches) in one manager, one step launch per batch per tick; the sphere query of
     configs[4] runs inside the step kernels.  Launch-bound populations: the batches are concurrent branches of ONE
@@ -426,7 +474,7 @@ def run_mixed(te, torch, name, steps, warmup, dist=None, rank=0, world=1, stream
     dt = 1.0 / 250.0
     es = 8 if dtype == "f64" else 4
     gb = block_ticks(steps)
-    if launch_mode == "graph":
+    if launch_mode in ("graph", "live"):
         ticks = gb
     else:
         ticks = max(2, min(stream_ticks, steps + warmup, RING_BYTES // (7 * es * n_all)))
@@ -473,6 +521,10 @@ def run_mixed(te, torch, name, steps, warmup, dist=None, rank=0, world=1, stream
                 mgr.step_sequence_all(dt, [m[:count] for m in meas], query=query, use_graph=0)
                 count = 0
 
+    if launch_mode == "live":
+        if intersect:
+            raise RuntimeError("the live mode has no fused sphere query yet")
+        return run_live_mixed(te, torch, name, desc, parts, dtype, mgr, batches, meas, dt, n_all, world, steps, warmup, reps, ticks)
     if launch_mode == "graph":
         mgr.step_sequence_all(dt, meas, query=query, use_graph=2)    # record before the timed region
         if passes > 1:
@@ -1091,7 +1143,11 @@ def main():
                 r = run_mixed(te, torch, name, 512 if small else args.extra_steps, 64 if small else 8, dist, rank, world,
                               launch_mode="auto" if args.launch_mode in ("fused", "live") else args.launch_mode, reps=3)
             elif name.endswith("_live"):                    # the resident mode of a small batch (never `value`)
-                r = run_workload(te, torch, name[:-len("_live")], args.extra_steps, 64, 0, dist=dist, rank=rank, world=world, launch_mode="live", reps=5)
+                wl = name[:-len("_live")]
+                if wl in MIXED:
+                    r = run_mixed(te, torch, wl, args.extra_steps, 64, dist, rank, world, launch_mode="live", reps=5)
+                else:
+                    r = run_workload(te, torch, wl, args.extra_steps, 64, 0, dist=dist, rank=rank, world=world, launch_mode="live", reps=5)
                 r["name"] = name
             elif name.endswith("_strong"):                  # strong scaling: the workload's targets split over the ranks
                 wl = name[:-len("_strong")]

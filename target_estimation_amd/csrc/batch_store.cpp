@@ -182,6 +182,8 @@ Batch::~Batch() {
   if (h_done_) (void)hipHostFree(h_done_);
   if (live_.h_posted) (void)hipHostFree(live_.h_posted);
   (void)hipFree(live_.d_block);
+  if (live_.stream) (void)hipStreamDestroy(live_.stream);
+  if (live_.ready) (void)hipEventDestroy(live_.ready);
 }
 
 long Batch::zigzag_min_bytes() {
@@ -577,7 +579,14 @@ void Batch::live_start(double dt, const void* meas_ring, long tick_stride, long 
   __atomic_store_n(live_.h_posted, 0LL, __ATOMIC_RELAXED);
   __atomic_store_n(live_.h_done, 0, __ATOMIC_RELAXED);
   __atomic_thread_fence(__ATOMIC_SEQ_CST);
-  TE_HIP_CHECK(hipMemsetAsync(live_.d_block, 0, 64 + sizeof(int) * (size_t)waves, stream_));   // mirror + progress: zero before EVERY launch
+  // The resident kernel gets a stream of its own (non-blocking), ordered behind everything already queued on the batch's
+  // stream: nothing the caller queues later on that stream -- for this batch's siblings in the manager, say -- waits for the
+  // session, and two batches of one manager can be resident together.
+  if (!live_.stream) TE_HIP_CHECK(hipStreamCreateWithFlags(&live_.stream, hipStreamNonBlocking));
+  if (!live_.ready) TE_HIP_CHECK(hipEventCreateWithFlags(&live_.ready, hipEventDisableTiming));
+  TE_HIP_CHECK(hipEventRecord(live_.ready, stream_));
+  TE_HIP_CHECK(hipStreamWaitEvent(live_.stream, live_.ready, 0));
+  TE_HIP_CHECK(hipMemsetAsync(live_.d_block, 0, 64 + sizeof(int) * (size_t)waves, live_.stream));   // mirror + progress: zero before EVERY launch
   StepParams p = base_params();
   p.meas = meas_ring; p.meas_ld = ld; p.has_meas = has_ring; p.dt = dt;
   p.n_ticks = (int)max_ticks; p.tick_stride = tick_stride; p.has_stride = has_stride;
@@ -588,7 +597,7 @@ void Batch::live_start(double dt, const void* meas_ring, long tick_stride, long 
   const double polls = idle_limit_s > 0 ? idle_limit_s * 5e5 : 5e6;
   p.live_spin_limit = (unsigned)std::min(polls, 4.0e9);
   { const char* e = std::getenv("TE_LIVE_FLAGS"); p.live_flags = e ? std::atoi(e) : 0; }
-  ops_->step(p, stream_);   // (the measured-pose rows are not kept during a live session: see measured_pose.hpp)
+  ops_->step(p, live_.stream);   // (the measured-pose rows are not kept during a live session: see measured_pose.hpp)
   TE_HIP_CHECK(hipGetLastError());
   live_.active = true; live_.waves = waves; live_.posted = 0; live_.max_ticks = max_ticks; live_.dt = dt;
   live_.all_measured = has_ring == nullptr;
@@ -620,7 +629,7 @@ long Batch::live_stop() {
   if (!live_.active) return 0;
   __atomic_store_n(live_.h_posted, (long long)live_.posted | kLiveStop, __ATOMIC_RELEASE);
   live_.active = false;     // whatever happens below, the session is over (flush() must not come back here)
-  TE_HIP_CHECK(hipStreamSynchronize(stream_));   // bounded: every wavefront drains the posted ticks, then sees the stop bit
+  TE_HIP_CHECK(hipStreamSynchronize(live_.stream));   // bounded: every wavefront drains the posted ticks, then sees the stop bit
   // the relay's last word: the ticks EVERY wavefront served.  The host's stop, or the relay's own after a silent host, reaches
   // all workers through one device word, so they all stop at the same tick.
   const long mn = (long)__atomic_load_n(live_.h_done, __ATOMIC_ACQUIRE);

@@ -294,6 +294,8 @@ class Batch {
     int* h_done = nullptr;
     int* d_done = nullptr;
     char* d_block = nullptr;         // device memory: [mirror word, padded to 64 B][progress words of the wavefronts]
+    hipStream_t stream = nullptr;    // the resident kernel's own stream
+    hipEvent_t ready = nullptr;
     long waves = 0, cap_waves = 0;
     long posted = 0, max_ticks = 0;
     double dt = 0.0;

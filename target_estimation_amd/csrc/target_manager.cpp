@@ -1204,6 +1204,76 @@ void TargetManager::stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpe
     if (batches_[b]->size() > 0) batches_[b]->account_sequence(n_ticks, dt, specs[b].meas_base && !specs[b].has_base);
 }
 
+void TargetManager::liveStartAll(double dt, const Batch::SeqSpec* specs, long n_specs, long first_entry, long max_ticks, double idle_limit_s) {
+  lock_guard<mutex> lg(target_lock_);
+  const size_t nb = batches_.size();
+  if ((size_t)n_specs != nb || nb == 0) throw std::runtime_error("target_estimation_amd: liveStartAll needs one spec per batch");
+  double share = 0.0;
+  for (size_t b = 0; b < nb; ++b) {
+    if (batches_[b]->size() == 0) throw std::runtime_error("target_estimation_amd: liveStartAll: an empty batch");
+    if (specs[b].ring_ticks <= 0) throw std::invalid_argument("target_estimation_amd: liveStartAll: every batch needs a measurement ring");
+    const long cap = batches_[b]->live_capacity_targets();
+    if (cap <= 0) throw std::runtime_error("target_estimation_amd: live mode needs the axis-separable layout with packed groups (batch " + std::to_string(b) + ")");
+    share += (double)(batches_[b]->size() + batches_[b]->layout().tpw) / (double)cap;   // + one tile for the relay wavefront
+  }
+  if (share > 1.0)
+    throw std::runtime_error("target_estimation_amd: liveStartAll: the batches' resident kernels do not fit the device together (" +
+                             std::to_string(share) + " of its capacity)");
+  size_t started = 0;
+  try {
+    for (; started < nb; ++started)
+      batches_[started]->live_start(dt, specs[started].meas_base, specs[started].tick_stride, specs[started].ld, specs[started].has_base,
+                                    specs[started].has_stride, specs[started].ring_ticks, first_entry, max_ticks, idle_limit_s);
+  } catch (...) {
+    for (size_t b = 0; b < started; ++b) { try { batches_[b]->live_stop(); } catch (...) {} }
+    throw;
+  }
+}
+
+void TargetManager::livePostAll(long n_ticks, bool one_doorbell_per_tick) {
+  lock_guard<mutex> lg(target_lock_);
+  if (one_doorbell_per_tick) {
+    for (long i = 0; i < n_ticks; ++i)
+      for (auto& b : batches_) b->live_post(1);
+  } else {
+    for (auto& b : batches_) b->live_post(n_ticks);
+  }
+}
+
+long TargetManager::liveDoneAll() {
+  long mn = -1;
+  for (auto& b : batches_) {
+    if (!b->live_active()) continue;
+    const long d = b->live_done();
+    mn = mn < 0 ? d : std::min(mn, d);
+  }
+  return mn < 0 ? 0 : mn;
+}
+
+bool TargetManager::liveWaitAll(long tick, double timeout_s) {
+  for (auto& b : batches_)
+    if (b->live_active() && !b->live_wait(tick, timeout_s)) return false;
+  return true;
+}
+
+long TargetManager::liveStopAll() {
+  lock_guard<mutex> lg(target_lock_);
+  long served = -1;
+  std::string err;
+  for (auto& b : batches_) {
+    if (!b->live_active()) continue;
+    try {
+      const long k = b->live_stop();
+      if (served >= 0 && k != served) err = "target_estimation_amd: liveStopAll: the batches served different numbers of ticks";
+      served = k;
+    } catch (const std::exception& e) {
+      err = e.what();
+    }
+  }
+  if (!err.empty()) throw std::runtime_error(err);
+  return served < 0 ? 0 : served;
+}
+
 void TargetManager::synchronize() {
   lock_guard<mutex> lg(target_lock_);
   for (auto& b : batches_) b->synchronize();

@@ -149,6 +149,15 @@ class TargetManager {
   void stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpec* specs, long n_specs, bool query,
                        const double* origin, double radius, int use_graph);
 
+  // Resident ("live") mode for EVERY batch of the manager at once (Batch::live_start per batch, each kernel on its own
+  // stream so that they are resident together): BASELINE configs[3] / configs[4] put two motion models on every GPU, and
+  // their per-GPU share (62 500 + 62 500 targets) is launch-bound.  specs as for stepSequenceAll (ring_ticks > 0 required).
+  // The wavefronts of all sessions must fit the device together: sum over batches of waves / capacity <= 1.
+  void liveStartAll(double dt, const Batch::SeqSpec* specs, long n_specs, long first_entry, long max_ticks, double idle_limit_s);
+  void livePostAll(long n_ticks, bool one_doorbell_per_tick);
+  long liveDoneAll();                       // ticks every wavefront of every batch has finished
+  bool liveWaitAll(long tick, double timeout_s);
+  long liveStopAll();                       // returns the ticks served (the same for every batch)
   int numBatches() const { return (int)batches_.size(); }
   Batch* batch(int i) { return batches_[(size_t)i].get(); }
   Batch* batchOfType(int type);

@@ -445,6 +445,32 @@ long target_batch_live_capacity(target_batch_c* b) {
   return guarded_value<long>("target_batch_live_capacity", -1L, [&] { return B(b)->live_capacity_targets(); });
 }
 
+int target_manager_live_start_all(target_manager_c* m, double dt, const target_batch_sequence_c* per_batch, long n_batches, long first_entry,
+                                  long max_ticks, double idle_limit_s) {
+  return guarded("target_manager_live_start_all", [&] {
+    if (!per_batch || n_batches <= 0) throw std::invalid_argument("NULL per-batch description");
+    std::vector<Batch::SeqSpec> specs((size_t)n_batches);
+    for (long i = 0; i < n_batches; ++i)
+      specs[(size_t)i] = Batch::SeqSpec{per_batch[i].meas_dev, per_batch[i].tick_stride, per_batch[i].ld, per_batch[i].has_meas_dev,
+                                        per_batch[i].has_stride, nullptr, nullptr, per_batch[i].ring_ticks};
+    M(m)->liveStartAll(dt, specs.data(), n_batches, first_entry, max_ticks, idle_limit_s);
+  });
+}
+int target_manager_live_post_all(target_manager_c* m, long n_ticks, int one_doorbell_per_tick) {
+  return guarded("target_manager_live_post_all", [&] { M(m)->livePostAll(n_ticks, one_doorbell_per_tick != 0); });
+}
+long target_manager_live_done_all(target_manager_c* m) {
+  return guarded_value<long>("target_manager_live_done_all", -1L, [&] { return M(m)->liveDoneAll(); });
+}
+int target_manager_live_wait_all(target_manager_c* m, long tick, double timeout_s) {
+  int late = 0;
+  const int rc = guarded("target_manager_live_wait_all", [&] { late = M(m)->liveWaitAll(tick, timeout_s) ? 0 : 1; });
+  return rc != 0 ? rc : late;
+}
+long target_manager_live_stop_all(target_manager_c* m) {
+  return guarded_value<long>("target_manager_live_stop_all", -1L, [&] { return M(m)->liveStopAll(); });
+}
+
 int target_batch_get_est_dev(target_batch_c* b, double* pose_dev, double* twist_dev, double* acc_dev, int at_time, double t1) {
   return guarded("target_batch_get_est_dev", [&] { BatchLock lk(B(b)); B(b)->outputs_dev(pose_dev, twist_dev, acc_dev, at_time != 0, t1); });
 }

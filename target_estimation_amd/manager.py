@@ -517,6 +517,33 @@ class TargetManager:
             self._h, ticks, float(dt), C.cast(specs, C.c_void_p), nb, 0 if query is None else 1,
             None if origin is None else _dp(origin), float(radius), int(use_graph)), "target_manager_step_sequence_all")
 
+    # ---- resident ("live") mode of every batch at once (target_batch_c.h)
+    def live_start_all(self, dt, meas, has_meas=None, first_entry=0, max_ticks=1 << 30, idle_limit_s=10.0):
+        """meas: one CUDA ring tensor [ring_ticks, 7, ld] per batch (batches() order)."""
+        nb = len(meas)
+        specs = (capi.BatchSequence * max(nb, 1))()
+        for i, t in enumerate(meas):
+            assert t.is_cuda and t.dim() == 3 and t.shape[1] == 7 and t.stride(2) == 1
+            specs[i].meas_dev, specs[i].tick_stride, specs[i].ld, specs[i].ring_ticks = t.data_ptr(), t.stride(0), t.stride(1), t.shape[0]
+            if has_meas is not None and has_meas[i] is not None:
+                h = has_meas[i]
+                assert h.is_cuda and h.dim() == 2 and h.element_size() == 1 and h.shape[0] == t.shape[0]
+                specs[i].has_meas_dev, specs[i].has_stride = h.data_ptr(), h.stride(0)
+        _check(self._lib.target_manager_live_start_all(self._h, float(dt), C.cast(specs, C.c_void_p), nb, int(first_entry), int(max_ticks),
+                                                       float(idle_limit_s)), "target_manager_live_start_all")
+
+    def live_post_all(self, n_ticks=1, one_doorbell_per_tick=False):
+        _check(self._lib.target_manager_live_post_all(self._h, int(n_ticks), 1 if one_doorbell_per_tick else 0), "target_manager_live_post_all")
+
+    def live_done_all(self):
+        return self._lib.target_manager_live_done_all(self._h)
+
+    def live_wait_all(self, tick, timeout_s=5.0):
+        return _check(self._lib.target_manager_live_wait_all(self._h, int(tick), float(timeout_s)), "target_manager_live_wait_all") == 0
+
+    def live_stop_all(self):
+        return _check(self._lib.target_manager_live_stop_all(self._h), "target_manager_live_stop_all")
+
     def batches(self):
         return [Batch(self._lib, self._lib.target_manager_get_batch(self._h, i))
                 for i in range(self._lib.target_manager_num_batches(self._h))]

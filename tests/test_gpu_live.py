@@ -176,3 +176,70 @@ def test_an_abandoned_session_ends_by_itself(models):
     x, P = mgr.get_state_batch(ids[:10])
     assert np.isfinite(x).all() and np.isfinite(P).all()
     mgr.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_two_models_resident_together_on_the_default_stream(models, dtype):
+    """BASELINE configs[3] at its per-GPU share (62 500 angular-rates + 62 500 angular-velocities): both batches of ONE manager
+    in live mode at the same time (each resident kernel on its own stream), the manager itself on the default stream, other
+    work of the manager going on meanwhile; against the all-batches call with a launch per tick, bit for bit, and the oracle."""
+    import bench
+    from target_estimation_amd.streams import make_stream
+    parts = bench.MIXED["cfg4"][1]
+    if dtype == "f64":
+        # the fp64 angular kernels hold a wavefront's state in 262 / 282 registers: one wavefront per SIMD, and 2 x 977 of them
+        # (+ relays) are more than the device holds at once -- the manager must say so instead of starting a session that
+        # cannot be fully resident
+        big, bmeas, _ = None, None, None
+        mgr = te.TargetManager(dtype=dtype)
+        rings, base = [], 0
+        for k, (name, n) in enumerate(parts):
+            m = models[name]
+            ids = np.arange(n, dtype=np.uint32) + base
+            base += n
+            mgr.init_batch(ids, 0.004, 0.0, np.tile([0, 0, 0, 0, 0, 0, 1.0], (n, 1)), type=m["model"], Q=m["Q"], R=m["R"], P0=m["P"])
+            rings.append(torch.zeros((2, 7, n), dtype=torch.float64, device="cuda"))
+        with pytest.raises(RuntimeError, match="do not fit the device together"):
+            mgr.live_start_all(0.004, rings)
+        assert not any(b._lib.target_batch_live_done(b._h) for b in mgr.batches())
+        mgr.close()
+        parts = [(name, 20_000) for name, _ in parts]
+    ticks, dt = 12, 0.004
+
+    def build():
+        mgr = te.TargetManager(dtype=dtype)
+        base, meas, info = 0, [], []
+        for k, (name, n) in enumerate(parts):
+            m = models[name]
+            st = make_stream(MODELS[name], n, ticks, dt, 300 + k, dtype=dtype)
+            ids = np.arange(n, dtype=np.uint32) + base
+            base += n
+            p0 = st["p0"].cpu().numpy()
+            mgr.init_batch(ids, dt, 0.0, p0, type=m["model"], Q=m["Q"], R=m["R"], P0=m["P"])
+            meas.append(st["meas"])
+            info.append((name, ids, p0, 300 + k))
+        return mgr, meas, info
+    ref, rmeas, _ = build()
+    ref.step_sequence_all(dt, rmeas, use_graph=0)
+    mgr, meas, info = build()
+    torch.cuda.synchronize()
+    mgr.live_start_all(dt, meas, max_ticks=ticks, idle_limit_s=3.0)
+    mgr.live_post_all(5, one_doorbell_per_tick=True)
+    assert mgr.live_wait_all(5, 5.0) and mgr.live_done_all() >= 5
+    assert mgr.size() == sum(n for _, n in parts)                  # a call that does not touch the batches leaves the sessions alone
+    assert all(b.live_done() >= 5 for b in mgr.batches())
+    mgr.live_post_all(ticks - 5)
+    assert mgr.live_wait_all(ticks, 5.0)
+    assert mgr.live_stop_all() == ticks
+    for (name, ids, p0, seed), b in zip(info, mgr.batches()):
+        got, want = mgr.get_state_batch(ids[::37]), ref.get_state_batch(ids[::37])
+        np.testing.assert_array_equal(got[0], want[0])
+        np.testing.assert_array_equal(got[1], want[1])
+        m = models[name]
+        sample = np.arange(0, len(ids), 400)
+        rs = oracle.stream_sample(m["model"], seed, sample, ticks, dt, dtype=dtype)
+        orc = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], p0[sample], dt, dtype=dtype)
+        for s in range(ticks):
+            orc.step(dt, rs["meas"][s])
+        check_state(mgr, ids[sample], orc, dtype, "%s, two models resident together" % name)
+    ref.close(); mgr.close()
