@@ -75,8 +75,11 @@ bool target_manager_get_est_acceleration(const target_manager_c *self, const uns
  * target_manager.cpp:285-295. */
 int  target_manager_get_n_measurements(const target_manager_c *self, const unsigned int id);
 
-/* rt_logger hook of the reference (target_manager_c.h:36 / target_manager_c.cpp:67-71); the
- * logger is an optional external ROS package there and out of scope here: exported no-op. */
+/* rt_logger hook of the reference (target_manager_c.h:36 / target_manager_c.cpp:67-71).  The logger is an
+ * optional external ROS package there (LOGGER_ON); here, without a log directory the call does nothing, as
+ * the reference without LOGGER_ON, and with one (target_manager_set_log_directory in target_batch_c.h, or env
+ * TARGET_ESTIMATION_LOG_DIR) it appends the reference's five channels -- measurement, pose, twist,
+ * acceleration, covariance (src/target_interface.cpp:32-40) -- of the selected targets to text files. */
 void target_manager_log(const target_manager_c *self);
 
 /* Destroy the manager and free its device memory.

@@ -516,9 +516,9 @@ void Batch::enqueue_tick(hipStream_t st, long s, double dt, const SeqSpec& q, bo
     p.q_origin[0] = origin[0]; p.q_origin[1] = origin[1]; p.q_origin[2] = origin[2];
     p.q_radius = radius; p.q_delta = q.delta_dev; p.q_pose = q.pose_dev;
   }
-  if (ab) p.rec_out = alt_records();
+  if (ab && !p.q_delta) p.rec_out = alt_records();   // (the fused query's kernels have no A -> B form: in place)
   launch_step(p, st);
-  if (ab) std::swap(d_rec_, d_rec_alt_);
+  if (p.rec_out) std::swap(d_rec_, d_rec_alt_);
   if (query && !fused_q) {
     IntersectArgs a;
     a.rec = d_rec_; a.idx = nullptr; a.n = n_; a.t1 = std::numeric_limits<double>::quiet_NaN();

@@ -67,7 +67,8 @@ struct OpsImpl {
     const int wpb_dense = waves <= small_grid ? 1 : C::WPB;
     const unsigned blocks = (unsigned)((waves + wpb_dense - 1) / wpb_dense);
     if (p.n_ticks > 1 && p.idx) throw std::runtime_error("target_estimation_amd: fused multi-tick launches are dense only");
-    if (p.rec_out && (p.idx || p.n_ticks > 1)) throw std::runtime_error("target_estimation_amd: A -> B ticks are dense single-tick launches");
+    if (p.rec_out && (p.idx || p.n_ticks > 1 || p.q_delta))
+      throw std::runtime_error("target_estimation_amd: A -> B ticks are dense single-tick launches without the fused query");
     // A few temporally fused instantiations do not fit the register file and would spill hundreds of bytes per lane to
     // scratch (228 / 116 / 340 / 352 B): for them a fused request is served tick by tick -- same results.
     constexpr bool kFusedSpills = (M::TYPE == ANGULAR_RATES && sizeof(T) == 8 && G == 3 && LAYOUT == LAYOUT_PACKED) ||
@@ -94,8 +95,12 @@ struct OpsImpl {
       const dim3 blk(64 * wpb);
       if (p.cls && p.idx)
         hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, true, false, false, true>), dim3(b4), blk, 0, s, a);
+      else if (p.cls && p.rec_out)
+        hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, false, false, false, true, false, true>), dim3(b4), blk, 0, s, a);
       else if (p.cls)
         hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, false, false, false, true>), dim3(b4), blk, 0, s, a);
+      else if (p.rec_out)
+        hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, false, false, false, false, false, true>), dim3(b4), blk, 0, s, a);
       else if (p.n_ticks > 1)
         hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, false, true>), dim3(b4), blk, 0, s, a);
       else if (p.idx)
@@ -107,8 +112,12 @@ struct OpsImpl {
     } else {
       if (p.cls && p.idx)
         hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, true, false, false, true>), dim3(blocks), dim3(wpb_dense * 64), 0, s, a);
+      else if (p.cls && p.rec_out)
+        hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, false, false, false, true, true>), dim3(blocks), dim3(wpb_dense * 64), 0, s, a);
       else if (p.cls)
         hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, false, false, false, true>), dim3(blocks), dim3(wpb_dense * 64), 0, s, a);
+      else if (p.rec_out)
+        hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, false, false, false, false, true>), dim3(blocks), dim3(wpb_dense * 64), 0, s, a);
       else if (p.n_ticks > 1) {
         if constexpr (!kFusedSpills)
           hipLaunchKernelGGL((kf_step_kernel<M, T, G, LAYOUT, false, true>), dim3(blocks), dim3(wpb_dense * 64), 0, s, a);

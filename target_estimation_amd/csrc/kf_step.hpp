@@ -281,12 +281,20 @@ __device__ __forceinline__ void signal_done(int* flag, int seq, int lane) {
 // the upper triangle with 6 lanes per target: unconstrained it takes 262 registers (one wavefront per SIMD, 1034 us per
 // 10^6-target tick); held to 256 it parks four doubles in scratch (32-56 B per lane) and runs two wavefronts: 647 us.
 // (The thread-per-target symmetric EKF got under the limit by other means: opaque_copy above and kf_model_av_sym.hip.)
+// see LATE_MEAS in kf_step_kernel
+template <class M, typename T, int G, int LAYOUT>
+constexpr bool kLateMeas = (M::TYPE == ANGULAR_RATES && LAYOUT == LAYOUT_PACKED && G == 6 && sizeof(T) == 8);
+
 template <class M, typename T, int G, int LAYOUT>
 constexpr int step_min_waves() { return (M::TYPE == ANGULAR_RATES && LAYOUT == LAYOUT_PACKED && G == 6 && sizeof(T) == 8) ? 2 : 1; }
 
-template <class M, typename T, int G, int LAYOUT, bool INDEXED, bool FUSED = false, bool QUERY = false, bool PERQR = false>
+// AB: an A -> B tick (StepArgs::rec_out).  Its own instantiation, not a run-time branch around the record stores: with the
+// branch some kernels kept both store sequences' operands alive and fell to one wavefront per SIMD (angular_rates fp32 on
+// the upper triangle, 3 lanes per target: 242 -> 299 registers, 304 -> 513 us per 10^6-target tick).
+template <class M, typename T, int G, int LAYOUT, bool INDEXED, bool FUSED = false, bool QUERY = false, bool PERQR = false, bool AB = false>
 __global__ void __launch_bounds__((Cfg<M, T, G, LAYOUT>::WPB * 64), (step_min_waves<M, T, G, LAYOUT>()))
 kf_step_kernel(const StepArgs<T> a) {
+  static_assert(!AB || (!INDEXED && !FUSED && !QUERY), "A -> B ticks are dense single-tick launches without the fused query");
   using C = Cfg<M, T, G, LAYOUT>;
   constexpr bool PK = C::PK;
   // the EKF on a symmetric-packed covariance, thread per target: works on the triangle in place (ekf_sym.hpp)
@@ -431,11 +439,16 @@ kf_step_kernel(const StepArgs<T> a) {
   const unsigned char* has_t = a.has_meas ? a.has_meas + (long)tick * a.has_stride : nullptr;
   // Every measurement word this lane needs is requested up front, right behind the record loads and
   // regardless of the mask (one round trip instead of one per use; see kf_step_sep.hpp).
+  // LATE_MEAS (angular_rates fp64 on the upper triangle, 6 lanes per target): the kernel sits at the two-wave register limit,
+  // and five measurement doubles (then three angles and a position word) held across the whole predict were what pushed
+  // four doubles of the record into scratch -- 10 % more HBM traffic than the record itself.  There the measurement is
+  // requested behind the predict instead; the other wavefront of the SIMD covers the round trip.
+  constexpr bool LATE_MEAS = kLateMeas<M, T, G, LAYOUT> && !FUSED;
   T ymeas_own[KPL], qmeas[4] = {0, 0, 0, 1};
 #pragma unroll
   for (int qq = 0; qq < KPL; ++qq) ymeas_own[qq] = 0;
   unsigned char hmask = 1;
-  if (valid && meas_t != nullptr) {
+  auto load_measurement = [&]() {
 #pragma unroll
     for (int qq = 0; qq < KPL; ++qq) {
       const int r = i + G * qq;
@@ -445,6 +458,9 @@ kf_step_kernel(const StepArgs<T> a) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) qmeas[c] = load_meas(&meas_t[(long)(3 + c) * a.meas_ld + entry], a.nt_meas);
     }
+  };
+  if (valid && meas_t != nullptr) {
+    if constexpr (!LATE_MEAS) load_measurement();
     if (has_t != nullptr) hmask = has_t[entry];
   }
   const bool has = valid && meas_t != nullptr && hmask != 0;
@@ -453,7 +469,7 @@ kf_step_kernel(const StepArgs<T> a) {
   // ------------------------------------------------------------------ measurement conversion
   // angular models: quaternion -> normalise -> rpy (every lane of the group redundantly)
   T mrpy[3] = {0, 0, 0};
-  if constexpr (M::ANGULAR) {
+  if constexpr (M::ANGULAR && !LATE_MEAS) {
     if (has) {
       T q[4];
       q[0] = qmeas[0];
@@ -616,6 +632,14 @@ kf_step_kernel(const StepArgs<T> a) {
   }
 
   // ------------------------------------------------------------------ update (estimate)
+  if constexpr (LATE_MEAS) {
+    if (has) {
+      load_measurement();
+      T q[4] = {qmeas[0], qmeas[1], qmeas[2], qmeas[3]};
+      quat_normalize(q);
+      quat_to_rpy(q, mrpy);
+    }
+  }
   if (has) {
     // S = P^-[0:K,0:K] + R and its inverse by unpivoted in-place Gauss-Jordan (S is SPD).
     //  LOCAL_INV (G == 1, or K == 3): every lane holds all of S and inverts it privately (one LDS
@@ -817,12 +841,8 @@ kf_step_kernel(const StepArgs<T> a) {
 #pragma unroll
       for (int w = 0; w < C::RW; ++w) mem[w] = rec[w];
     }
-    if constexpr (!INDEXED) {
-      if (a.rec_out != nullptr) store_record<C, T, EKF_SYM, true>(a.rec_out + tile * C::TILE_BYTES, lt, mem);   // A -> B tick (StepArgs::rec_out)
-      else store_record<C, T, EKF_SYM>(tb, lt, mem);
-    } else {
-      store_record<C, T, EKF_SYM>(tb, lt, mem);
-    }
+    if constexpr (AB) store_record<C, T, EKF_SYM, true>(a.rec_out + tile * C::TILE_BYTES, lt, mem);   // A -> B tick (StepArgs::rec_out)
+    else store_record<C, T, EKF_SYM>(tb, lt, mem);
     if (i == 0) {
       if constexpr (INDEXED) {
         const long slot = slot_of;

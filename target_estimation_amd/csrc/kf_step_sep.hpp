@@ -88,8 +88,10 @@ constexpr int sep_min_waves() { return (PERQR && M::TYPE == ANGULAR_RATES && siz
 
 // LIVE: a resident launch (StepArgs::live_*): the tick loop of FUSED with a wait for the host's doorbell in front of every tick
 // and a progress word behind it.  Same arithmetic per tick, same results as single ticks.
-template <class M, typename T, int LAYOUT, bool INDEXED, bool FUSED = false, bool QUERY = false, bool PERQR = false, bool LIVE = false>
+// AB: an A -> B tick (StepArgs::rec_out), its own instantiation (see kf_step_kernel).
+template <class M, typename T, int LAYOUT, bool INDEXED, bool FUSED = false, bool QUERY = false, bool PERQR = false, bool LIVE = false, bool AB = false>
 __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR>())) kf_step_sep_kernel(const StepArgs<T> a) {
+  static_assert(!AB || (!INDEXED && !FUSED && !QUERY && !LIVE), "A -> B ticks are dense single-tick launches without the fused query");
   static_assert(!(QUERY && (INDEXED || FUSED)), "the fused query is for dense single-tick launches");
   static_assert(!(PERQR && (FUSED || QUERY)), "per-class Q/R: single-tick launches without the fused query");
   static_assert(!LIVE || (FUSED && !INDEXED && !QUERY && !PERQR), "live launches are dense multi-tick launches");
@@ -491,12 +493,8 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR>())) k
   }
   }  // tick loop
   if (valid) {
-    if constexpr (!INDEXED) {
-      if (a.rec_out != nullptr) store_record<C, T, false, true>(a.rec_out + tile * C::TILE_BYTES, lt, mem);   // A -> B tick (StepArgs::rec_out)
-      else store_record<C, T>(tb, lt, mem);
-    } else {
-      store_record<C, T>(tb, lt, mem);
-    }
+    if constexpr (AB) store_record<C, T, false, true>(a.rec_out + tile * C::TILE_BYTES, lt, mem);   // A -> B tick (StepArgs::rec_out)
+    else store_record<C, T>(tb, lt, mem);
     if constexpr (QUERY) {
       T xq[N];
 #pragma unroll
