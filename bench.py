@@ -845,7 +845,7 @@ def load_traffic():
 
 
 def attach_traffic(kernels, workload, traffic):
-    rows = traffic.get(workload, {})
+    rows = traffic.get(workload, {}) if not workload.startswith("_") else {}
     for k in kernels:
         t = rows.get(k["kernel"])
         k["traffic"] = (t["hbm_read_bytes"] + t["hbm_write_bytes"]) if t else None

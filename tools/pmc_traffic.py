@@ -78,7 +78,13 @@ def main():
     args.out = os.path.abspath(args.out)   # rocprofv3 runs with cwd = /tmp
     os.makedirs(args.out, exist_ok=True)
     result, failures = {}, []
-    for wl in [w for w in args.workloads.split(",") if w]:
+    try:   # the commit the snapshot on this box was taken at (written before the gpurun call; there is no .git here)
+        commit = open(os.path.join(ROOT, ".head_commit")).read().strip()
+    except OSError:
+        commit = "unknown"
+    result["_meta"] = {"commit": commit, "tool": "tools/pmc_traffic.py", "counters": "FETCH_SIZE x 2 x 1024, WRITE_SIZE x 1024 (MI355X_MICROARCH.md, HBM)"}
+    # the resident (live) and free-running (replay) extras are ONE launch for many ticks: no per-tick launch to attribute counters to
+    for wl in [w for w in args.workloads.split(",") if w and not w.endswith("_live") and not w.endswith("_replay")]:
         per = {}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             rc, rows = one_pass(wl, counter, args.out, args.steps, [])

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round-3 evidence at HEAD, one gpurun call: (1) the default bench line + side file, (2) rocprofv3 --kernel-trace --stats of the same
+# command, (3) ONE all-in-one --pmc FETCH_SIZE pass over the whole default process, (4) FETCH_SIZE / WRITE_SIZE passes for every
+# workload of the line (tools/pmc_traffic.py -> hbm_traffic.json with the commit in _meta).
+set -o pipefail
+OUT=$PWD/gpurun_out/r3final
+mkdir -p $OUT
+export TMPDIR=/tmp
+echo "== default bench" | tee $OUT/progress.txt
+timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 --side-file $OUT/bench_extra.json > $OUT/bench_line.json 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/progress.txt
+tail -c 2500 $OUT/bench_line.json
+echo "== kernel trace" | tee -a $OUT/progress.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --side-file $OUT/bench_extra_trace.json > $OUT/bench_trace.json 2> $OUT/bench_trace.err
+echo "trace rc=$?" | tee -a $OUT/progress.txt
+python3 tools/summarize_trace.py $OUT/trace $OUT/bench_trace.json > $OUT/bench_default_rocprofv3.txt 2>> $OUT/progress.txt
+find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/bench_default_kernel_stats.csv \;
+rm -rf $OUT/trace
+echo "== all-in-one PMC pass (once)" | tee -a $OUT/progress.txt
+TE_BENCH_MAPS=$OUT/allinone_maps.txt timeout -k 10 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/allinone -o allinone -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --side-file $OUT/bench_extra_allinone.json > $OUT/allinone.json 2> $OUT/allinone.err
+echo "all-in-one rc=$?" | tee -a $OUT/progress.txt
+tail -3 $OUT/allinone_maps.txt.progress 2>/dev/null | tee -a $OUT/progress.txt
+rm -rf $OUT/allinone
+echo "== traffic" | tee -a $OUT/progress.txt
+timeout -k 10 2400 python3 tools/pmc_traffic.py --out $OUT/pmc > $OUT/pmc_traffic.txt 2>&1; echo "traffic rc=$?" | tee -a $OUT/progress.txt
+tail -5 $OUT/pmc_traffic.txt
+du -sh $OUT
