@@ -20,7 +20,5 @@ TE_BENCH_MAPS=$OUT/allinone_maps.txt timeout -k 10 900 rocprofv3 --kernel-trace 
 echo "all-in-one rc=$?" | tee -a $OUT/progress.txt
 tail -3 $OUT/allinone_maps.txt.progress 2>/dev/null | tee -a $OUT/progress.txt
 rm -rf $OUT/allinone
-echo "== traffic" | tee -a $OUT/progress.txt
-timeout -k 10 2400 python3 tools/pmc_traffic.py --out $OUT/pmc > $OUT/pmc_traffic.txt 2>&1; echo "traffic rc=$?" | tee -a $OUT/progress.txt
-tail -5 $OUT/pmc_traffic.txt
+# (4) runs as separate gpurun calls (a call is limited to 20 minutes): python3 tools/pmc_traffic.py --out gpurun_out/r3final/pmcA --workloads ...
 du -sh $OUT
