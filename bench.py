@@ -1168,8 +1168,8 @@ def main():
         tr = [k.get("traffic") for k in r["kernels"]]
         extras.append({k: r[k] for k in ("name", "dtype", "targets_per_gpu", "layout", "kernel", "cycles_per_s", "ms_per_step",
                                         "device_ms_per_step", "achieved_gbs", "algorithmic_bytes_per_cycle", "residency", "launch_mode")}
-                      | ({"live": r["live"]} if "live" in r else {})
-                      | {"roofline_frac": r["achieved_gbs"] / HBM_PEAK_GBS, "n_gpus": world,
+                      | ({"live": r["live"], "achieved_gbs": None} if "live" in r else {})   # a resident launch moves the measurements only: no per-tick HBM figure
+                      | {"roofline_frac": None if "live" in r else r["achieved_gbs"] / HBM_PEAK_GBS, "n_gpus": world,
                          "traffic_per_step": (sum(tr) if all(t is not None for t in tr) else None)})
         torch.cuda.empty_cache()
         maps_checkpoint(name)
@@ -1193,9 +1193,9 @@ def main():
         side["extra"] = extras
         # the HBM-bound rows (state > 1 GB) apart, where a reader finds them
         side["roofline"]["hbm_bound"] = {e["name"]: {"achieved": e["achieved_gbs"], "frac": e["roofline_frac"], "cycles_per_s": e["cycles_per_s"]}
-                                         for e in extras if "error" not in e and e.get("residency", "").startswith("HBM-bound") and not e["name"].endswith("_replay")}
+                                         for e in extras if "error" not in e and e.get("residency", "").startswith("HBM-bound") and not e["name"].endswith("_replay") and "live" not in e}
         side["roofline"]["l3_assisted"] = {e["name"]: {"achieved": e["achieved_gbs"], "frac": e["roofline_frac"], "cycles_per_s": e["cycles_per_s"]}
-                                           for e in extras if "error" not in e and e.get("residency", "").startswith("L3-assisted") and not e["name"].endswith("_replay")}
+                                           for e in extras if "error" not in e and e.get("residency", "").startswith("L3-assisted") and not e["name"].endswith("_replay") and "live" not in e}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
