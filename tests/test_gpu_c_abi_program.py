@@ -64,3 +64,22 @@ def test_cpp_example_of_the_batch_api(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert "5000 targets, 256 ticks" in out.stdout and "predict+update cycles/s" in out.stdout
     assert "512 measurements" in out.stdout          # 256 timed + 4 warm-up blocks of 64 ticks
+
+
+@pytest.mark.parametrize("name,n,steps", [("uniform_velocity", 10000, 1000), ("angular_rates", 4000, 300)])
+def test_cpp_example_of_the_resident_mode(tmp_path, name, n, steps):
+    """examples/live_stream.cpp: the resident mode, the stream generator and the round-3 getters from plain C++ (hipcc, no
+    Python): a session served through a ring that is refilled behind it equals the same ticks as single launches, bit for bit."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    libdir = os.path.join(ROOT, "target_estimation_amd", "lib")
+    exe = str(tmp_path / "live_stream")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-w",
+                           "-I", os.path.join(ROOT, "include", "target_estimation_amd"),
+                           os.path.join(ROOT, "examples", "live_stream.cpp"), "-o", exe,
+                           "-L", libdir, "-ltarget_estimation_amd", "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe, model_path(name), str(n), str(steps)], capture_output=True, text=True, timeout=300)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "live stream example ok" in out.stdout and "%d ticks served" % steps in out.stdout
