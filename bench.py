@@ -126,7 +126,7 @@ MIXED = {
 }
 HEADLINE = "cfg4_1gpu"
 
-DEFAULT_EXTRA = ("cfg2,cfg2_live,cfg2_stream,cfg3,cfg3_live,cfg3_stream,cfg4,cfg4_live,cfg4_64,cfg5,cfg4_1gpu32,cfg5_1gpu,cfg5_1gpu64,"
+DEFAULT_EXTRA = ("cfg2,cfg2_live,cfg2_stream,cfg3,cfg3_live,cfg3_stream,cfg4,cfg4_live,cfg4_64,cfg5,cfg5_live,cfg4_1gpu32,cfg5_1gpu,cfg5_1gpu64,"
                  "uv1m,uv1m32,ua1m64,ua1m,av1m64,av1m,ar1m64,ar1m,"
                  "uv10m,ua10m,av4m64,ar4m64,av8m,ar8m,cfg4_4m,"
                  "ar1m_a90,av1m_a90,ar1m64_1kcls,ar1m64_1kcls_rand,ar100k64_1kcls,uv1m_1kcls,uv1m_full,uv1m_packed,ar1m_full,ar1m_packed,av1m_packed,ar1m64_full,av1m64_full,ar1m64_packed,av1m64_packed")
@@ -407,10 +407,11 @@ def run_live(te, torch, name, desc, model, dtype, mgr, b, meas, has, ids, dt, n_
     return res
 
 
-def run_live_mixed(te, torch, name, desc, parts, dtype, mgr, batches, meas, dt, n_all, world, steps, warmup, reps, ring_ticks):
-    """run_live for every batch of a manager at once (target_manager_live_*_all): one resident kernel per motion model."""
+def run_live_mixed(te, torch, name, desc, parts, dtype, mgr, batches, meas, dt, n_all, world, steps, warmup, reps, ring_ticks, query=None, outs=None):
+    """run_live for every batch of a manager at once (target_manager_live_*_all): one resident kernel per motion model; with
+    `query` the own-time sphere query of every target runs after every tick inside them (configs[4])."""
     torch.cuda.synchronize()
-    mgr.live_start_all(dt, meas, max_ticks=1 << 30, idle_limit_s=10.0)
+    mgr.live_start_all(dt, meas, max_ticks=1 << 30, idle_limit_s=10.0, query=query)
     posted = [0]
 
     def back_to_back(count):
@@ -443,9 +444,11 @@ def run_live_mixed(te, torch, name, desc, parts, dtype, mgr, batches, meas, dt, 
         p, _, _ = b.get_est(twist=False, acc=False)
         assert torch.isfinite(p).all()
     models = [m for m, _ in parts]
-    kernels = [kernel_name(b, m) + " (LIVE variant)" for b, m in zip(batches, models)]
+    kernels = [kernel_name(b, m) + " (LIVE variant)" + ("+query" if query else "") for b, m in zip(batches, models)]
     res = summarize(name, desc, models, dtype, batches, kernels, n_all, world, k, wall, [w * 1e3 for w in wall],
                     "live: one resident launch per motion model, one tick per doorbell, back to back")
+    if query:
+        res["intersections_last_tick"] = sum(int((o[0] > -1).sum()) for o in outs)
     res.update(measurement_ring_ticks=ring_ticks, measurement_ring_bytes=int(sum(m.numel() * m.element_size() for m in meas)),
                live=dict(ticks_per_region=k, us_per_tick_back_to_back=median(wall) / k * 1e6, us_per_tick_back_to_back_min=min(wall) / k * 1e6,
                          us_per_tick_paced=median(wall_paced) / min(k, 2000) * 1e6, ticks_served=served,
@@ -522,9 +525,7 @@ def run_mixed(te, torch, name, steps, warmup, dist=None, rank=0, world=1, stream
                 count = 0
 
     if launch_mode == "live":
-        if intersect:
-            raise RuntimeError("the live mode has no fused sphere query yet")
-        return run_live_mixed(te, torch, name, desc, parts, dtype, mgr, batches, meas, dt, n_all, world, steps, warmup, reps, ticks)
+        return run_live_mixed(te, torch, name, desc, parts, dtype, mgr, batches, meas, dt, n_all, world, steps, warmup, reps, ticks, query, outs)
     if launch_mode == "graph":
         mgr.step_sequence_all(dt, meas, query=query, use_graph=2)    # record before the timed region
         if passes > 1:

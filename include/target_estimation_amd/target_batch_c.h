@@ -285,11 +285,13 @@ int target_manager_step_sequence_all(target_manager_c* m, long n_ticks, double d
                                      long n_batches, int query, const double* origin, double radius, int use_graph);
 /* Resident ("live") mode (target_batch_live_* above) for EVERY batch of a manager at once (BASELINE.json configs[3] / configs[4]: two motion models per GPU, whose per-GPU
  * share is launch-bound): one resident kernel per batch, each on a stream of its own so that they are on the device together;
- * per_batch[i] describes batch i's ring as for target_manager_step_sequence_all (ring_ticks > 0, no query outputs).  The
+ * per_batch[i] describes batch i's ring as for target_manager_step_sequence_all (ring_ticks > 0); with query != 0 the own-time
+ * sphere query of every target runs after every tick inside the resident kernels, into per_batch[i].delta_dev / pose_dev
+ * (overwritten every tick), as target_manager_step_sequence_all's fused query does.  The
  * sessions' wavefronts must fit the device together.  ..._post_all: n_ticks to every batch (one_doorbell_per_tick != 0: as
  * n_ticks separate doorbells); ..._done_all: ticks finished by every wavefront of every batch; ..._stop_all: ticks served. */
 int target_manager_live_start_all(target_manager_c* m, double dt, const target_batch_sequence_c* per_batch, long n_batches, long first_entry,
-                                  long max_ticks, double idle_limit_s);
+                                  long max_ticks, double idle_limit_s, int query, const double* origin, double radius);
 int target_manager_live_post_all(target_manager_c* m, long n_ticks, int one_doorbell_per_tick);
 long target_manager_live_done_all(target_manager_c* m);
 int target_manager_live_wait_all(target_manager_c* m, long tick, double timeout_s);

@@ -547,8 +547,10 @@ void Batch::step_fused(long n_ticks, double dt, const void* meas_base, long tick
 }
 
 void Batch::live_start(double dt, const void* meas_ring, long tick_stride, long ld, const unsigned char* has_ring, long has_stride,
-                       long ring_ticks, long first_entry, long max_ticks, double idle_limit_s) {
+                       long ring_ticks, long first_entry, long max_ticks, double idle_limit_s, const double* q_origin, double q_radius,
+                       double* q_delta_dev, double* q_pose_dev) {
   touch();   // ends a previous session, runs queued one-target steps
+  if (q_delta_dev && !q_origin) throw std::invalid_argument("target_estimation_amd: live_start: query without an origin");
   if (n_ == 0) throw std::runtime_error("target_estimation_amd: live mode on an empty batch");
   if (!meas_ring || ring_ticks <= 0 || max_ticks <= 0 || first_entry < 0 || ld < n_ || tick_stride < 7 * ld || (has_ring && has_stride < n_))
     throw std::invalid_argument("target_estimation_amd: live_start: bad measurement ring");
@@ -597,6 +599,10 @@ void Batch::live_start(double dt, const void* meas_ring, long tick_stride, long 
   const double polls = idle_limit_s > 0 ? idle_limit_s * 5e5 : 5e6;
   p.live_spin_limit = (unsigned)std::min(polls, 4.0e9);
   { const char* e = std::getenv("TE_LIVE_FLAGS"); p.live_flags = e ? std::atoi(e) : 0; }
+  if (q_delta_dev) {
+    p.q_origin[0] = q_origin[0]; p.q_origin[1] = q_origin[1]; p.q_origin[2] = q_origin[2];
+    p.q_radius = q_radius; p.q_delta = q_delta_dev; p.q_pose = q_pose_dev;
+  }
   ops_->step(p, live_.stream);   // (the measured-pose rows are not kept during a live session: see measured_pose.hpp)
   TE_HIP_CHECK(hipGetLastError());
   live_.active = true; live_.waves = waves; live_.posted = 0; live_.max_ticks = max_ticks; live_.dt = dt;

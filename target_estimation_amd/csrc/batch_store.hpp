@@ -88,8 +88,11 @@ class Batch {
   // on the batch (steps, getters, erase, ...) ends the session first.  The whole grid must be resident (the wavefronts wait
   // for the host, not for each other, but one that never starts would miss its ticks): refused beyond live_capacity().
   // A wavefront that sees no news for idle_limit_s gives up on its own (a dead host leaves no kernel behind).
+  // q_delta_dev [size] (+ q_pose_dev [size][7] or null): also run the own-time sphere query of every target after every tick
+  // (outputs overwritten every tick), as enqueue_tick's fused query does
   void live_start(double dt, const void* meas_ring, long tick_stride, long ld, const unsigned char* has_ring, long has_stride,
-                  long ring_ticks, long first_entry, long max_ticks, double idle_limit_s);
+                  long ring_ticks, long first_entry, long max_ticks, double idle_limit_s, const double* q_origin = nullptr,
+                  double q_radius = 0.0, double* q_delta_dev = nullptr, double* q_pose_dev = nullptr);
   void live_post(long n_ticks);
   long live_done() const;
   bool live_wait(long tick, double timeout_s) const;

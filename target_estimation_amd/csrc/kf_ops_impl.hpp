@@ -45,7 +45,7 @@ struct OpsImpl {
     a.live_spin_limit = p.live_spin_limit; a.live_flags = p.live_flags;
     if (p.live_posted) {   // resident launch: one wavefront per workgroup, every workgroup resident (Batch::live_start checked the capacity)
       if constexpr (kHasLive) {
-        if (p.idx || p.cls || p.q_delta || p.rec_out || !p.live_progress || !p.live_mirror || !p.live_done || p.live_ring <= 0 || p.n_ticks < 1)
+        if (p.idx || p.cls || p.rec_out || !p.live_progress || !p.live_mirror || !p.live_done || p.live_ring <= 0 || p.n_ticks < 1)
           throw std::runtime_error("target_estimation_amd: a live launch is a dense launch of a one-class batch over a measurement ring");
         const long waves_live = (p.n + C::TPW - 1) / C::TPW;
         // + 1: the relay wavefront (kf_step.hpp live_relay)

@@ -488,7 +488,16 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR>())) k
     }
   }
 
-  if constexpr (LIVE) {   // tick `tick` is done (state in registers): a word in device memory for the relay
+  if constexpr (LIVE) {
+    // the own-time sphere query of every target after every tick (BASELINE configs[4]), on the posterior still in registers;
+    // a run-time choice here: the resident kernel exists once per (model, precision)
+    if (a.q_delta != nullptr && valid) {
+      T xq[N];
+#pragma unroll
+      for (int r = 0; r < N; ++r) xq[r] = XW_(r);
+      sphere_query<M, T>(xq, true, 0.0, 0.0, a.q_origin, a.q_radius, &a.q_delta[entry], a.q_pose ? &a.q_pose[entry * 7] : nullptr);
+    }
+    // tick `tick` is done (state in registers): a word in device memory for the relay
     if (lane == 0) __hip_atomic_store(&a.live_progress[wave_id], tick + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   }  // tick loop

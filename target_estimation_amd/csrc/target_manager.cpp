@@ -1204,10 +1204,14 @@ void TargetManager::stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpe
     if (batches_[b]->size() > 0) batches_[b]->account_sequence(n_ticks, dt, specs[b].meas_base && !specs[b].has_base);
 }
 
-void TargetManager::liveStartAll(double dt, const Batch::SeqSpec* specs, long n_specs, long first_entry, long max_ticks, double idle_limit_s) {
+void TargetManager::liveStartAll(double dt, const Batch::SeqSpec* specs, long n_specs, long first_entry, long max_ticks, double idle_limit_s,
+                                 bool query, const double* origin, double radius) {
   lock_guard<mutex> lg(target_lock_);
   const size_t nb = batches_.size();
   if ((size_t)n_specs != nb || nb == 0) throw std::runtime_error("target_estimation_amd: liveStartAll needs one spec per batch");
+  if (query && !origin) throw std::runtime_error("target_estimation_amd: liveStartAll: query without an origin");
+  for (size_t b = 0; b < nb; ++b)
+    if (query && !specs[b].delta_dev) throw std::runtime_error("target_estimation_amd: liveStartAll: query without a delta output");
   double share = 0.0;
   for (size_t b = 0; b < nb; ++b) {
     if (batches_[b]->size() == 0) throw std::runtime_error("target_estimation_amd: liveStartAll: an empty batch");
@@ -1223,7 +1227,9 @@ void TargetManager::liveStartAll(double dt, const Batch::SeqSpec* specs, long n_
   try {
     for (; started < nb; ++started)
       batches_[started]->live_start(dt, specs[started].meas_base, specs[started].tick_stride, specs[started].ld, specs[started].has_base,
-                                    specs[started].has_stride, specs[started].ring_ticks, first_entry, max_ticks, idle_limit_s);
+                                    specs[started].has_stride, specs[started].ring_ticks, first_entry, max_ticks, idle_limit_s,
+                                    query ? origin : nullptr, radius, query ? specs[started].delta_dev : nullptr,
+                                    query ? specs[started].pose_dev : nullptr);
   } catch (...) {
     for (size_t b = 0; b < started; ++b) { try { batches_[b]->live_stop(); } catch (...) {} }
     throw;

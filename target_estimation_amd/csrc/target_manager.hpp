@@ -153,7 +153,9 @@ class TargetManager {
   // stream so that they are resident together): BASELINE configs[3] / configs[4] put two motion models on every GPU, and
   // their per-GPU share (62 500 + 62 500 targets) is launch-bound.  specs as for stepSequenceAll (ring_ticks > 0 required).
   // The wavefronts of all sessions must fit the device together: sum over batches of waves / capacity <= 1.
-  void liveStartAll(double dt, const Batch::SeqSpec* specs, long n_specs, long first_entry, long max_ticks, double idle_limit_s);
+  // query: also the own-time sphere query of every target after every tick into specs[b].delta_dev / pose_dev (configs[4])
+  void liveStartAll(double dt, const Batch::SeqSpec* specs, long n_specs, long first_entry, long max_ticks, double idle_limit_s,
+                    bool query = false, const double* origin = nullptr, double radius = 0.0);
   void livePostAll(long n_ticks, bool one_doorbell_per_tick);
   long liveDoneAll();                       // ticks every wavefront of every batch has finished
   bool liveWaitAll(long tick, double timeout_s);

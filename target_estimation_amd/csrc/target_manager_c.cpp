@@ -446,14 +446,14 @@ long target_batch_live_capacity(target_batch_c* b) {
 }
 
 int target_manager_live_start_all(target_manager_c* m, double dt, const target_batch_sequence_c* per_batch, long n_batches, long first_entry,
-                                  long max_ticks, double idle_limit_s) {
+                                  long max_ticks, double idle_limit_s, int query, const double* origin, double radius) {
   return guarded("target_manager_live_start_all", [&] {
     if (!per_batch || n_batches <= 0) throw std::invalid_argument("NULL per-batch description");
     std::vector<Batch::SeqSpec> specs((size_t)n_batches);
     for (long i = 0; i < n_batches; ++i)
       specs[(size_t)i] = Batch::SeqSpec{per_batch[i].meas_dev, per_batch[i].tick_stride, per_batch[i].ld, per_batch[i].has_meas_dev,
-                                        per_batch[i].has_stride, nullptr, nullptr, per_batch[i].ring_ticks};
-    M(m)->liveStartAll(dt, specs.data(), n_batches, first_entry, max_ticks, idle_limit_s);
+                                        per_batch[i].has_stride, per_batch[i].delta_dev, per_batch[i].pose_dev, per_batch[i].ring_ticks};
+    M(m)->liveStartAll(dt, specs.data(), n_batches, first_entry, max_ticks, idle_limit_s, query != 0, origin, radius);
   });
 }
 int target_manager_live_post_all(target_manager_c* m, long n_ticks, int one_doorbell_per_tick) {

@@ -518,8 +518,9 @@ class TargetManager:
             None if origin is None else _dp(origin), float(radius), int(use_graph)), "target_manager_step_sequence_all")
 
     # ---- resident ("live") mode of every batch at once (target_batch_c.h)
-    def live_start_all(self, dt, meas, has_meas=None, first_entry=0, max_ticks=1 << 30, idle_limit_s=10.0):
-        """meas: one CUDA ring tensor [ring_ticks, 7, ld] per batch (batches() order)."""
+    def live_start_all(self, dt, meas, has_meas=None, first_entry=0, max_ticks=1 << 30, idle_limit_s=10.0, query=None):
+        """meas: one CUDA ring tensor [ring_ticks, 7, ld] per batch (batches() order).  query = (origin[3], radius, deltas, poses)
+        adds the own-time sphere query of every target after every tick (as step_sequence_all's)."""
         nb = len(meas)
         specs = (capi.BatchSequence * max(nb, 1))()
         for i, t in enumerate(meas):
@@ -529,8 +530,16 @@ class TargetManager:
                 h = has_meas[i]
                 assert h.is_cuda and h.dim() == 2 and h.element_size() == 1 and h.shape[0] == t.shape[0]
                 specs[i].has_meas_dev, specs[i].has_stride = h.data_ptr(), h.stride(0)
+        origin, radius = None, 0.0
+        if query is not None:
+            origin, radius, deltas, poses = query
+            origin = _d(origin, (3,))
+            for i in range(nb):
+                specs[i].delta_dev = deltas[i].data_ptr()
+                specs[i].pose_dev = None if poses is None or poses[i] is None else poses[i].data_ptr()
         _check(self._lib.target_manager_live_start_all(self._h, float(dt), C.cast(specs, C.c_void_p), nb, int(first_entry), int(max_ticks),
-                                                       float(idle_limit_s)), "target_manager_live_start_all")
+                                                       float(idle_limit_s), 0 if query is None else 1, None if origin is None else _dp(origin),
+                                                       float(radius)), "target_manager_live_start_all")
 
     def live_post_all(self, n_ticks=1, one_doorbell_per_tick=False):
         _check(self._lib.target_manager_live_post_all(self._h, int(n_ticks), 1 if one_doorbell_per_tick else 0), "target_manager_live_post_all")

@@ -243,3 +243,63 @@ def test_two_models_resident_together_on_the_default_stream(models, dtype):
             orc.step(dt, rs["meas"][s])
         check_state(mgr, ids[sample], orc, dtype, "%s, two models resident together" % name)
     ref.close(); mgr.close()
+
+
+def test_config4_share_resident_with_the_per_tick_query(models):
+    """BASELINE configs[4] at its per-GPU share (62 500 angular-rates + 62 500 uniform-acceleration, fp32, the sphere query of
+    every target after every tick): both batches resident, the query inside the resident kernels, against the all-batches
+    call with a launch per tick (state, delta and pose after the last tick: bit for bit) and the oracle."""
+    import bench
+    from target_estimation_amd.streams import make_stream
+    parts, dtype = bench.MIXED["cfg5"][1], "f32"
+    ticks, dt = 9, 0.004
+    origin, radius = np.zeros(3), 5.0
+
+    def build():
+        mgr = te.TargetManager(dtype=dtype)
+        base, meas, info = 0, [], []
+        for k, (name, n) in enumerate(parts):
+            m = models[name]
+            st = make_stream(MODELS[name], n, ticks, dt, 700 + k, dtype=dtype)
+            ids = np.arange(n, dtype=np.uint32) + base
+            base += n
+            p0 = st["p0"].cpu().numpy()
+            rng = np.random.default_rng(40 + k)             # inbound, accelerating targets: the query has roots to find
+            d = p0[:, :3] / np.linalg.norm(p0[:, :3], axis=1, keepdims=True)
+            v0 = np.concatenate([-d * rng.uniform(1, 6, (n, 1)), np.zeros((n, 3))], 1)
+            a0 = np.concatenate([rng.normal(0, 1.0, (n, 3)) + [0, 0, -2.0], np.zeros((n, 3))], 1)
+            mgr.init_batch(ids, dt, 0.0, p0, v0, a0, type=m["model"], Q=m["Q"], R=m["R"], P0=m["P"])
+            meas.append(st["meas"])
+            info.append((name, ids, p0, v0, a0, 700 + k))
+        deltas = [torch.full((b.size,), 123.0, dtype=torch.float64, device="cuda") for b in mgr.batches()]
+        poses = [torch.zeros((b.size, 7), dtype=torch.float64, device="cuda") for b in mgr.batches()]
+        return mgr, meas, info, deltas, poses
+    ref, rmeas, _, rd, rp = build()
+    ref.step_sequence_all(dt, rmeas, query=(origin, radius, rd, rp), use_graph=0)
+    mgr, meas, info, dd, pp = build()
+    torch.cuda.synchronize()
+    mgr.live_start_all(dt, meas, max_ticks=ticks, idle_limit_s=3.0, query=(origin, radius, dd, pp))
+    mgr.live_post_all(ticks, one_doorbell_per_tick=True)
+    assert mgr.live_wait_all(ticks, 5.0) and mgr.live_stop_all() == ticks
+    torch.cuda.synchronize()
+    hits = 0
+    for j, (name, ids, p0, v0, a0, seed) in enumerate(info):
+        np.testing.assert_array_equal(dd[j].cpu().numpy(), rd[j].cpu().numpy())
+        np.testing.assert_array_equal(pp[j].cpu().numpy(), rp[j].cpu().numpy())
+        got, want = mgr.get_state_batch(ids[::53]), ref.get_state_batch(ids[::53])
+        np.testing.assert_array_equal(got[0], want[0])
+        np.testing.assert_array_equal(got[1], want[1])
+        m = models[name]
+        sample = np.arange(0, len(ids), 250)
+        rs = oracle.stream_sample(m["model"], seed, sample, ticks, dt, dtype=dtype)
+        orc = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], p0[sample], dt, 0.0, v0[sample], a0[sample], dtype=dtype)
+        for s in range(ticks):
+            orc.step(dt, rs["meas"][s])
+        ok_o, pose_o, delta_o = orc.intersection_pose(ticks * dt, origin, radius)
+        d = dd[j].cpu().numpy()[sample]
+        both = (d > -1) & (delta_o > -1)
+        assert ((d > -1) != (delta_o > -1)).mean() <= 0.01
+        np.testing.assert_allclose(d[both], delta_o[both], rtol=5e-4, atol=5e-4)
+        hits += int(both.sum())
+    assert hits > 50
+    ref.close(); mgr.close()
