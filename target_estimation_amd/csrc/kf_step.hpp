@@ -131,20 +131,11 @@ __device__ __forceinline__ void live_relay(const long long* posted, long long* m
                                            unsigned limit, int lane) {
   long long last = 0;
   int last_done = 0;
-  unsigned idle = 0, after_stop = 0;
+  unsigned idle = 0;   // consecutive rounds in which nothing happened: no news from the host, no progress of the workers
   for (;;) {
     long long v = 0;
     if (lane == 0) v = __hip_atomic_load(posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // one PCIe read per round
     v = wave_uniform_ll(v);
-    if (last < 0) v = last;                                  // stopping: the host's word no longer matters
-    else if (idle >= limit) v = last | kLiveStop;            // a silent host: stop the session at what was posted
-    if (v != last) {
-      if (lane == 0) __hip_atomic_store(mirror, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      last = v;
-      idle = 0;
-    } else {
-      ++idle;
-    }
     int mn = 0x7fffffff;
     for (long w = lane; w < waves; w += 64) {
       const int p = __hip_atomic_load(&progress[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -155,13 +146,26 @@ __device__ __forceinline__ void live_relay(const long long* posted, long long* m
       const int o = __shfl_xor(mn, off, 64);
       mn = o < mn ? o : mn;
     }
-    if (mn != last_done) {
+    const bool progressed = mn != last_done;
+    if (progressed) {
       if (lane == 0) __hip_atomic_store(done, mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // one PCIe write per change
       last_done = mn;
     }
+    const bool caught_up = (long long)mn >= (last & kLiveCount);
+    if (last < 0) v = last;                                    // stopping: the host's word no longer matters
+    else if (caught_up && idle >= limit) v = last | kLiveStop;  // everything served and a silent host: stop at what was posted
+    if (v != last) {
+      if (lane == 0) __hip_atomic_store(mirror, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = v;
+      idle = 0;
+    } else if (progressed) {
+      idle = 0;   // the workers are busy with ticks already posted: that is not an idle host
+    } else {
+      ++idle;
+    }
     if (last < 0) {
-      if ((long long)mn >= (last & kLiveCount)) break;       // every worker has served the posted ticks and is leaving
-      if (++after_stop >= limit) break;                      // (a worker that never ran: nothing more to wait for)
+      if ((long long)mn >= (last & kLiveCount)) break;   // every worker has served the posted ticks and is leaving
+      if (idle >= limit) break;                          // (a worker that never ran: nothing more to wait for)
     }
     __builtin_amdgcn_s_sleep(2);
   }
