@@ -668,6 +668,13 @@ long TargetManager::eraseBatch(const unsigned* ids, long n) {
     batches_[b]->erase_slots(slots[b].data(), (long)slots[b].size(), moves);
     for (auto const& mv : moves) targets_.set(mv.first, Loc{(int)b, mv.second});
   }
+  if (!log_files_.empty())
+    for (unsigned id : erased) {   // logged targets that went away close their files
+      auto lf = log_files_.find(id);
+      if (lf == log_files_.end()) continue;
+      for (std::FILE* f : lf->second.f) if (f) std::fclose(f);
+      log_files_.erase(lf);
+    }
   return (long)erased.size();
 }
 
@@ -1247,6 +1254,7 @@ void TargetManager::livePostAll(long n_ticks, bool one_doorbell_per_tick) {
 }
 
 long TargetManager::liveDoneAll() {
+  lock_guard<mutex> lg(target_lock_);
   long mn = -1;
   for (auto& b : batches_) {
     if (!b->live_active()) continue;
@@ -1257,8 +1265,13 @@ long TargetManager::liveDoneAll() {
 }
 
 bool TargetManager::liveWaitAll(long tick, double timeout_s) {
-  for (auto& b : batches_)
-    if (b->live_active() && !b->live_wait(tick, timeout_s)) return false;
+  std::vector<Batch*> open;   // the list under the lock, the spinning without it (posts come from other threads)
+  {
+    lock_guard<mutex> lg(target_lock_);
+    for (auto& b : batches_) if (b->live_active()) open.push_back(b.get());
+  }
+  for (Batch* b : open)
+    if (!b->live_wait(tick, timeout_s)) return false;
   return true;
 }
 
