@@ -137,9 +137,17 @@ __device__ __forceinline__ void live_relay(const long long* posted, long long* m
     if (lane == 0) v = __hip_atomic_load(posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // one PCIe read per round
     v = wave_uniform_ll(v);
     int mn = 0x7fffffff;
-    for (long w = lane; w < waves; w += 64) {
-      const int p = __hip_atomic_load(&progress[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      mn = p < mn ? p : mn;
+    // eight independent loads in flight per lane before the first is used (one after the other, 25 dependent L2 round trips
+    // made a 1563-wavefront round 17 us long)
+    for (long w0 = 0; w0 < waves; w0 += 64 * 8) {
+      int p[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const long w = w0 + (long)k * 64 + lane;
+        p[k] = w < waves ? __hip_atomic_load(&progress[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) mn = p[k] < mn ? p[k] : mn;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
