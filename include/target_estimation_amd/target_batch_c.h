@@ -260,6 +260,12 @@ int target_batch_step_fused(target_batch_c* b, long n_ticks, double dt, const vo
 int target_batch_live_start(target_batch_c* b, double dt, const void* meas_ring_dev, long tick_stride, long ld,
                             const unsigned char* has_ring_dev, long has_stride, long ring_ticks, long first_entry, long max_ticks,
                             double idle_limit_s);
+/* Per-tick pose output of the sessions started AFTER this call (also through target_manager_live_start_all): pose_soa_dev =
+ * device memory, SoA [7][ld] doubles (row c = component c of [x y z qx qy qz qw] for slots 0..size-1), NULL = off.  The resident
+ * kernel writes the estimated pose of every target after every tick -- what the reference's node publishes every tick
+ * (src/target_manager_ros.cpp:78-87) -- through the caches and before the tick counts as done: copy the buffer on another stream
+ * after ..._live_done reached tick k and it holds the poses of a tick >= k (exactly k when one tick is posted at a time). */
+int target_batch_live_set_pose_output(target_batch_c* b, double* pose_soa_dev, long ld);
 int target_batch_live_post(target_batch_c* b, long n_ticks);
 /* n_ticks doorbells of ONE tick each, back to back (what a caller's loop of ..._live_post(b, 1) does, without its call overhead) */
 int target_batch_live_post_each(target_batch_c* b, long n_ticks);

@@ -127,6 +127,7 @@ SIGNATURES = {
     "target_batch_step_fused": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long]),
     "target_batch_live_start": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_long,
                                           C.c_long, C.c_double]),
+    "target_batch_live_set_pose_output": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long]),
     "target_batch_live_post": (C.c_int, [C.c_void_p, C.c_long]),
     "target_batch_live_post_each": (C.c_int, [C.c_void_p, C.c_long]),
     "target_batch_live_done": (C.c_long, [C.c_void_p]),

@@ -599,6 +599,10 @@ void Batch::live_start(double dt, const void* meas_ring, long tick_stride, long 
   const double polls = idle_limit_s > 0 ? idle_limit_s * 5e5 : 5e6;
   p.live_spin_limit = (unsigned)std::min(polls, 4.0e9);
   { const char* e = std::getenv("TE_LIVE_FLAGS"); p.live_flags = e ? std::atoi(e) : 0; }
+  if (live_.pose_out) {
+    if (live_.pose_ld < n_) throw std::invalid_argument("target_estimation_amd: live pose output: rows shorter than the batch (it grew since live_set_pose_output)");
+    p.live_pose = live_.pose_out; p.live_pose_ld = live_.pose_ld;
+  }
   if (q_delta_dev) {
     p.q_origin[0] = q_origin[0]; p.q_origin[1] = q_origin[1]; p.q_origin[2] = q_origin[2];
     p.q_radius = q_radius; p.q_delta = q_delta_dev; p.q_pose = q_pose_dev;
@@ -607,6 +611,12 @@ void Batch::live_start(double dt, const void* meas_ring, long tick_stride, long 
   TE_HIP_CHECK(hipGetLastError());
   live_.active = true; live_.waves = waves; live_.posted = 0; live_.max_ticks = max_ticks; live_.dt = dt;
   live_.all_measured = has_ring == nullptr;
+}
+
+void Batch::live_set_pose_output(double* pose_soa_dev, long ld) {
+  if (pose_soa_dev && ld < n_) throw std::invalid_argument("target_estimation_amd: live pose output: rows shorter than the batch");
+  live_.pose_out = pose_soa_dev;
+  live_.pose_ld = pose_soa_dev ? ld : 0;
 }
 
 void Batch::live_post(long n_ticks) {

@@ -93,6 +93,11 @@ class Batch {
   void live_start(double dt, const void* meas_ring, long tick_stride, long ld, const unsigned char* has_ring, long has_stride,
                   long ring_ticks, long first_entry, long max_ticks, double idle_limit_s, const double* q_origin = nullptr,
                   double q_radius = 0.0, double* q_delta_dev = nullptr, double* q_pose_dev = nullptr);
+  // pose_soa_dev [7][ld] doubles (device memory; null switches it off): the sessions started AFTER this call also write the
+  // estimated pose of every target after every tick there (the reference's node publishes them every tick,
+  // src/target_manager_ros.cpp:78-87), through the caches and before the tick counts as done -- a consumer that copies the
+  // buffer on another stream after live_done() reached tick k reads the poses of a tick >= k (of tick k if it posts one tick at a time)
+  void live_set_pose_output(double* pose_soa_dev, long ld);
   void live_post(long n_ticks);
   long live_done() const;
   bool live_wait(long tick, double timeout_s) const;
@@ -297,6 +302,8 @@ class Batch {
     int* h_done = nullptr;
     int* d_done = nullptr;
     char* d_block = nullptr;         // device memory: [mirror word, padded to 64 B][progress words of the wavefronts]
+    double* pose_out = nullptr;      // per-tick pose output (live_set_pose_output)
+    long pose_ld = 0;
     hipStream_t stream = nullptr;    // the resident kernel's own stream
     hipEvent_t ready = nullptr;
     long waves = 0, cap_waves = 0;

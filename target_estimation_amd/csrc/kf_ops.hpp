@@ -47,6 +47,8 @@ struct StepParams {
   long live_ring = 0, live_first = 0;
   unsigned live_spin_limit = 0;
   int live_flags = 0;
+  double* live_pose = nullptr;   // SoA [7][live_pose_ld] per-tick pose output of a live launch, or null
+  long live_pose_ld = 0;
 };
 
 struct Ops {

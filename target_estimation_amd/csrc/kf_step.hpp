@@ -100,6 +100,11 @@ struct StepArgs {
   long live_first;
   unsigned live_spin_limit;
   int live_flags;   // experiments (TE_LIVE_FLAGS): 2 = plain measurement loads
+  // live_pose (or null): SoA [7][live_pose_ld] doubles in device memory that receives the estimated pose of every target after
+  // every tick (what the reference's node publishes every tick, src/target_manager_ros.cpp:78-87), written THROUGH the caches
+  // before the tick's progress word, so that a copy engine that reads it after `done` reached the tick sees that tick's poses
+  double* live_pose;
+  long live_pose_ld;
 };
 
 __device__ __forceinline__ long long wave_uniform_ll(long long v) {

@@ -498,6 +498,19 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR>())) k
       for (int r = 0; r < N; ++r) xq[r] = XW_(r);
       sphere_query<M, T>(xq, true, 0.0, 0.0, a.q_origin, a.q_radius, &a.q_delta[entry], a.q_pose ? &a.q_pose[entry * 7] : nullptr);
     }
+    if (a.live_pose != nullptr) {   // the tick's estimated poses for a consumer outside the kernel (StepArgs::live_pose)
+      if (valid) {
+        T xq[N], pose7[7], twist6[6], acc6[6];
+#pragma unroll
+        for (int r = 0; r < N; ++r) xq[r] = XW_(r);
+        derive_outputs<M, T>(xq, false, (T)0, pose7, twist6, acc6);
+#pragma unroll
+        for (int c = 0; c < 7; ++c)   // system-scope stores: written through to memory, 512 contiguous bytes per wavefront and row
+          __hip_atomic_store(reinterpret_cast<unsigned long long*>(&a.live_pose[(long)c * a.live_pose_ld + entry]),
+                             (unsigned long long)__double_as_longlong((double)pose7[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the rows have left before the progress word says so
+    }
     // tick `tick` is done (state in registers): a word in device memory for the relay
     if (lane == 0) __hip_atomic_store(&a.live_progress[wave_id], tick + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }

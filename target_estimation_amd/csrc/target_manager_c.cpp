@@ -424,6 +424,9 @@ int target_batch_live_start(target_batch_c* b, double dt, const void* meas_ring_
     B(b)->live_start(dt, meas_ring_dev, tick_stride, ld, has_ring_dev, has_stride, ring_ticks, first_entry, max_ticks, idle_limit_s);
   });
 }
+int target_batch_live_set_pose_output(target_batch_c* b, double* pose_soa_dev, long ld) {
+  return guarded("target_batch_live_set_pose_output", [&] { BatchLock lk(B(b)); B(b)->live_set_pose_output(pose_soa_dev, ld); });
+}
 int target_batch_live_post(target_batch_c* b, long n_ticks) {
   return guarded("target_batch_live_post", [&] { BatchLock lk(B(b)); B(b)->live_post(n_ticks); });
 }

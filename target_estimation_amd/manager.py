@@ -138,6 +138,15 @@ class Batch:
         _check(self._lib.target_batch_live_start(self._h, float(dt), meas_ring.data_ptr(), meas_ring.stride(0), meas_ring.stride(1), hp, hs,
                                                  meas_ring.shape[0], int(first_entry), int(max_ticks), float(idle_limit_s)), "target_batch_live_start")
 
+    def live_set_pose_output(self, pose_soa):
+        """pose_soa: CUDA double tensor [7, ld >= size] (or None): sessions started afterwards write every tick's poses there."""
+        if pose_soa is None:
+            _check(self._lib.target_batch_live_set_pose_output(self._h, None, 0), "target_batch_live_set_pose_output")
+            return
+        import torch
+        assert pose_soa.is_cuda and pose_soa.dtype == torch.float64 and pose_soa.dim() == 2 and pose_soa.shape[0] == 7 and pose_soa.stride(1) == 1
+        _check(self._lib.target_batch_live_set_pose_output(self._h, pose_soa.data_ptr(), pose_soa.stride(0)), "target_batch_live_set_pose_output")
+
     def live_post(self, n_ticks=1):
         _check(self._lib.target_batch_live_post(self._h, int(n_ticks)), "target_batch_live_post")
 

@@ -318,3 +318,39 @@ def test_a_busy_session_is_not_an_idle_one(models):
     x, P = mgr.get_state_batch(ids[:16])
     assert np.isfinite(x).all() and np.isfinite(P).all()
     mgr.close()
+
+
+@pytest.mark.parametrize("name,dtype,N", [("uniform_velocity", "f64", 10_000), ("angular_velocities", "f32", 30_000)])
+def test_per_tick_pose_output_of_a_live_session(models, name, dtype, N):
+    """The node loop of the reference publishes every target's filtered pose every tick (src/target_manager_ros.cpp:78-87).  A
+    live session writes them to a device buffer after every tick: posted one tick at a time, the buffer copied on a second stream
+    after each tick's completion holds exactly that tick's poses -- the getter's poses of a manager stepped by single launches,
+    bit for bit -- without ending the session."""
+    ticks, dt = 10, 0.004
+    mgr, b, st, ids, p0, live = _setup(models, name, dtype, N, ticks, dt, 61)
+    ref = te.TargetManager(model_path(name), dtype=dtype)
+    ref.init_batch(ids, dt, 0.0, p0)
+    rb = ref.batches()[0]
+    want = []
+    for s in range(ticks):
+        rb.step(dt, st["meas"][s])
+        want.append(rb.get_est(twist=False, acc=False)[0].cpu().numpy())       # [N, 7]
+    torch.cuda.synchronize()
+    ld = N + 13                                                                # a padded row length
+    pose_soa = torch.full((7, ld), float("nan"), dtype=torch.float64, device="cuda")
+    host = torch.empty((7, ld), dtype=torch.float64).pin_memory()
+    torch.cuda.synchronize()
+    copy = torch.cuda.Stream()
+    b.live_set_pose_output(pose_soa)
+    b.live_start(dt, st["meas"], max_ticks=ticks, idle_limit_s=3.0)
+    for s in range(ticks):
+        b.live_post(1)
+        assert b.live_wait(s + 1, 5.0)
+        with torch.cuda.stream(copy):
+            host.copy_(pose_soa, non_blocking=True)
+        copy.synchronize()
+        np.testing.assert_array_equal(host.numpy()[:, :N].T, want[s])
+        assert np.isnan(host.numpy()[:, N:]).all()                             # nothing beyond the batch is written
+    assert b.live_done() == ticks and b.live_stop() == ticks
+    b.live_set_pose_output(None)
+    ref.close(); mgr.close()
