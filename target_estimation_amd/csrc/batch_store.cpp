@@ -197,9 +197,14 @@ long Batch::pingpong_min_bytes() {
 }
 
 char* Batch::alt_records() {
-  if (!d_rec_alt_) {   // same capacity as d_rec_; zero-filled so that the idle lanes of a ragged last tile hold defined words
+  if (!d_rec_alt_ && !alt_failed_) {   // same capacity as d_rec_; zero-filled so that the idle lanes of a ragged last tile hold defined words
     const size_t bytes = (size_t)(cap_ / ops_->L.tpw) * (size_t)ops_->L.tile_bytes;
-    TE_HIP_CHECK(hipMalloc((void**)&d_rec_alt_, bytes));
+    if (hipMalloc((void**)&d_rec_alt_, bytes) != hipSuccess) {   // no room for a second copy of the state: stay in place (same results)
+      (void)hipGetLastError();
+      d_rec_alt_ = nullptr;
+      alt_failed_ = true;
+      return nullptr;
+    }
     TE_HIP_CHECK(hipMemsetAsync(d_rec_alt_, 0, bytes, stream_));
   }
   return d_rec_alt_;
@@ -255,7 +260,7 @@ void Batch::reserve(long n) {
   }
   TE_HIP_CHECK(hipStreamSynchronize(stream_));
   (void)hipFree(d_rec_); (void)hipFree(d_tbase_); (void)hipFree(d_nmbase_); (void)hipFree(d_cls_);
-  (void)hipFree(d_rec_alt_); d_rec_alt_ = nullptr;   // re-created at the new capacity by the next A -> B tick
+  (void)hipFree(d_rec_alt_); d_rec_alt_ = nullptr; alt_failed_ = false;   // re-created at the new capacity by the next A -> B tick
   if (keep_meas_) {
     double* lm = nullptr;
     TE_HIP_CHECK(hipMalloc((void**)&lm, sizeof(double) * 7 * (size_t)want));
@@ -446,7 +451,7 @@ void Batch::step_sequence(long n_ticks, double dt, const void* meas_base, long t
       StepParams p = params(s);
       if (ab) p.rec_out = alt_records();
       launch_step(p, stream_);
-      if (ab) std::swap(d_rec_, d_rec_alt_);
+      if (p.rec_out) std::swap(d_rec_, d_rec_alt_);
     }
     TE_HIP_CHECK(hipGetLastError());
     if (n_ticks & 1) flip_ = !flip_;

@@ -230,7 +230,8 @@ class Batch {
   int intern_p0(const double* P0);
   char* d_rec_ = nullptr;          // the CURRENT records (A -> B ticks swap it with d_rec_alt_ after every launch)
   char* d_rec_alt_ = nullptr;      // second record buffer of the same capacity, allocated on the first A -> B tick
-  char* alt_records();
+  char* alt_records();             // null if the device has no room for it (the batch then stays in place)
+  bool alt_failed_ = false;
   double* d_tbase_ = nullptr;
   int* d_nmbase_ = nullptr;
   long cap_ = 0;  // slots
