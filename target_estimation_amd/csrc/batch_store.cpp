@@ -551,6 +551,10 @@ void Batch::step_fused(long n_ticks, double dt, const void* meas_base, long tick
   if (meas_base && !has_base) nm_acc_ += n_ticks;
 }
 
+// device block of a live session: [one mirror word per kLiveGroup wavefronts, 128 bytes apart][progress words]
+static size_t live_mirror_bytes(long waves) { return (size_t)((waves + kLiveGroup - 1) / kLiveGroup) * kLiveMirrorStride * sizeof(long long); }
+static size_t live_block_bytes(long waves) { return (live_mirror_bytes(waves) + sizeof(int) * (size_t)waves + 15) / 16 * 16; }
+
 void Batch::live_start(double dt, const void* meas_ring, long tick_stride, long ld, const unsigned char* has_ring, long has_stride,
                        long ring_ticks, long first_entry, long max_ticks, double idle_limit_s, const double* q_origin, double q_radius,
                        double* q_delta_dev, double* q_pose_dev) {
@@ -580,7 +584,7 @@ void Batch::live_start(double dt, const void* meas_ring, long tick_stride, long 
     TE_HIP_CHECK(hipStreamSynchronize(stream_));
     (void)hipFree(live_.d_block);
     live_.d_block = nullptr;
-    TE_HIP_CHECK(hipMalloc((void**)&live_.d_block, 64 + sizeof(int) * (size_t)waves));
+    TE_HIP_CHECK(hipMalloc((void**)&live_.d_block, live_block_bytes(waves)));
     live_.cap_waves = waves;
   }
   __atomic_store_n(live_.h_posted, 0LL, __ATOMIC_RELAXED);
@@ -593,12 +597,12 @@ void Batch::live_start(double dt, const void* meas_ring, long tick_stride, long 
   if (!live_.ready) TE_HIP_CHECK(hipEventCreateWithFlags(&live_.ready, hipEventDisableTiming));
   TE_HIP_CHECK(hipEventRecord(live_.ready, stream_));
   TE_HIP_CHECK(hipStreamWaitEvent(live_.stream, live_.ready, 0));
-  TE_HIP_CHECK(hipMemsetAsync(live_.d_block, 0, 64 + sizeof(int) * (size_t)waves, live_.stream));   // mirror + progress: zero before EVERY launch
+  TE_HIP_CHECK(hipMemsetAsync(live_.d_block, 0, live_block_bytes(waves), live_.stream));   // mirrors + progress: zero before EVERY launch
   StepParams p = base_params();
   p.meas = meas_ring; p.meas_ld = ld; p.has_meas = has_ring; p.dt = dt;
   p.n_ticks = (int)max_ticks; p.tick_stride = tick_stride; p.has_stride = has_stride;
   p.live_posted = live_.d_posted; p.live_done = live_.d_done;
-  p.live_mirror = reinterpret_cast<long long*>(live_.d_block); p.live_progress = reinterpret_cast<int*>(live_.d_block + 64);
+  p.live_mirror = reinterpret_cast<long long*>(live_.d_block); p.live_progress = reinterpret_cast<int*>(live_.d_block + live_mirror_bytes(waves));
   p.live_ring = ring_ticks; p.live_first = first_entry % ring_ticks;
   // a poll is a PCIe round trip plus s_sleep: ~1-2 us; the limit is a count of polls
   const double polls = idle_limit_s > 0 ? idle_limit_s * 5e5 : 5e6;

@@ -85,9 +85,10 @@ struct StepArgs {
   // host memory costs 0.6-1.6 us and they serialise (measured: a progress word per worker wavefront per tick made a
   // 157-wavefront tick 250 us long), so the workers talk to device memory and the relay carries two words over PCIe:
   //   live_posted   host-mapped, host -> relay: ticks posted so far; sign bit = "stop once they are done"
-  //   live_mirror   device word, relay -> workers: the same value (the relay adds the stop bit itself when the host has
+  //   live_mirror   device words, relay -> workers: the same value (the relay adds the stop bit itself when the host has
   //                 been silent for live_spin_limit polls: a dead host leaves no kernel behind, and every worker stops at
-  //                 the same tick)
+  //                 the same tick).  One copy per kLiveGroup wavefronts, each in a 128-byte line of its own: 1563 wavefronts
+  //                 polling ONE word queue up at one memory channel (a paced 10^5-target tick took 21 us that way)
   //   live_progress device words [wavefronts], worker -> relay: ticks this wavefront has finished
   //   live_done     host-mapped, relay -> host: the minimum of live_progress
   //   live_ring / live_first   the measurement ring holds live_ring ticks; tick k of the session reads entry (live_first + k) % live_ring
@@ -138,22 +139,23 @@ __device__ __forceinline__ void live_relay(const long long* posted, long long* m
   int last_done = 0;
   unsigned idle = 0;   // consecutive rounds in which nothing happened: no news from the host, no progress of the workers
   for (;;) {
+    // One PCIe read per round, requested FIRST and consumed LAST: the scan of the workers' words below goes out behind it and
+    // the round costs the longer of the two round trips, not their sum.  The scan keeps up to 32 independent loads in flight per
+    // lane (one after the other, 25 dependent round trips made a 1563-wavefront round 17 us long).
     long long v = 0;
-    if (lane == 0) v = __hip_atomic_load(posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // one PCIe read per round
-    v = wave_uniform_ll(v);
+    if (lane == 0) v = __hip_atomic_load(posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     int mn = 0x7fffffff;
-    // eight independent loads in flight per lane before the first is used (one after the other, 25 dependent L2 round trips
-    // made a 1563-wavefront round 17 us long)
-    for (long w0 = 0; w0 < waves; w0 += 64 * 8) {
-      int p[8];
+    for (long w0 = 0; w0 < waves; w0 += 64 * 32) {
+      int p[32];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < 32; ++k) {
         const long w = w0 + (long)k * 64 + lane;
         p[k] = w < waves ? __hip_atomic_load(&progress[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) mn = p[k] < mn ? p[k] : mn;
+      for (int k = 0; k < 32; ++k) mn = p[k] < mn ? p[k] : mn;
     }
+    v = wave_uniform_ll(v);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       const int o = __shfl_xor(mn, off, 64);
@@ -168,7 +170,9 @@ __device__ __forceinline__ void live_relay(const long long* posted, long long* m
     if (last < 0) v = last;                                    // stopping: the host's word no longer matters
     else if (caught_up && idle >= limit) v = last | kLiveStop;  // everything served and a silent host: stop at what was posted
     if (v != last) {
-      if (lane == 0) __hip_atomic_store(mirror, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const long groups = (waves + kLiveGroup - 1) / kLiveGroup;
+      for (long g = lane; g < groups; g += 64)
+        __hip_atomic_store(&mirror[g * kLiveMirrorStride], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       last = v;
       idle = 0;
     } else if (progressed) {

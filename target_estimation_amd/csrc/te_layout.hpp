@@ -214,6 +214,8 @@ __host__ __device__ inline long record_word_offset(int lane, int w) {
 // the doorbell word of a resident ("live") launch (kf_step.hpp StepArgs::live_posted): ticks posted | stop bit
 constexpr long long kLiveStop = (long long)(1ull << 63);    // sign bit: "stop once the posted ticks are done"
 constexpr long long kLiveCount = (long long)(~(1ull << 63));
+constexpr int kLiveGroup = 32;           // worker wavefronts that share one copy of the relay's mirror word
+constexpr int kLiveMirrorStride = 16;    // long longs between copies (128 bytes: a line of its own each)
 
 struct LayoutInfo {
   int n, m, g, layout, tpw, lpt, record_words;
