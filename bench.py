@@ -1113,14 +1113,14 @@ def main():
         except Exception as exc:
             side["roofline"]["copy_bandwidth_error"] = str(exc)[:200]
     maps_checkpoint(args.workload)
-    # N > 1: the scaling line goes out FIRST (the driver's curve must not depend on anything below); the extras, and the
-    # one RCCL exchange the path offers, come after it and land in the side file.
-    if world > 1:
-        if dist is not None:
-            dist.barrier()
-        if rank == 0:
-            emit(compact_line(out))
-            write_side(args, dict(side, line=out))
+    # The line goes out FIRST, as soon as it is complete: neither the driver's record (N = 1) nor its scaling curve (N > 1) may
+    # depend on anything below.  The extras -- and for N > 1 the one RCCL exchange the path offers -- come after it and land in
+    # the side file.
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        emit(compact_line(out))
+        write_side(args, dict(side, line=out))
     # Extra workloads.  One GPU: the full list.  Several GPUs: one 10^6-targets-per-GPU workload per YAML motion model plus
     # the configs' per-GPU shares, every rank in lockstep (same barriers, max over ranks).
     extra_names = [e for e in (args.extra if world == 1 else args.extra_multi).split(",") if e]
@@ -1203,8 +1203,6 @@ def main():
     if rank == 0:
         write_side(args, dict(side, line=out))
         print(json.dumps(dict(side, line=out)), file=sys.stderr)
-        if world == 1:
-            emit(compact_line(out))
 
 
 if __name__ == "__main__":
