@@ -206,3 +206,81 @@ def test_log_of_a_large_population_is_one_file_per_channel(tmp_path, models):
     Po = orc.state()[1].reshape(N, 144)
     np.testing.assert_allclose(cov[N:, 1:], Po, rtol=6e-6, atol=1e-9 * np.abs(Po).max())
     mgr.close()
+
+
+def test_measured_pose_through_fused_and_sequence_launches(models):
+    """The measured-pose rows behind multi-tick launches: a temporally fused launch (several ticks in one kernel) and a recorded
+    sequence, with availability masks -- every target must end with the LAST measurement it actually had (updateMeasurement
+    semantics, src/target_interface.cpp:142-146), targets without any keep the initial pose."""
+    from target_estimation_amd.streams import make_stream
+    name, N, T, dt = "angular_rates", 700, 6, 0.004
+    m = models[name]
+    st = make_stream(m["model"], N, T, dt, 17, availability=0.5)
+    ref = oracle.stream_fill(m["model"], 17, N, T, dt, availability=0.5)
+    has = ref["has_meas"].copy()
+    has[:, :5] = 0                                  # five targets never measured
+    has_dev = torch.from_numpy(has).cuda()
+    ids = np.arange(N, dtype=np.uint32)
+    for mode in ("fused", "graph"):
+        mgr = te.TargetManager(model_path(name))
+        mgr.set_keep_measurement(True)
+        mgr.init_batch(ids, dt, 0.0, ref["p0"])
+        b = mgr.batches()[0]
+        if mode == "fused":
+            b.step_fused(dt, st["meas"], has_dev)
+        else:
+            b.step_sequence(dt, st["meas"], has_dev, use_graph=True)
+        orc = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], ref["p0"], dt)
+        for s in range(T):
+            orc.step(dt, ref["meas"][s], has[s])
+        mo = orc.measured_pose()
+        for i in list(range(8)) + [N // 2, N - 1]:
+            np.testing.assert_array_equal(mgr.getMeasuredPose(int(i))[1], mo[i])
+        np.testing.assert_array_equal(mgr.getMeasuredPose(2)[1], [0, 0, 0, 0, 0, 0, 1.0])
+        assert mgr.getNumberMeasurements(2) == 0 and mgr.getNumberMeasurements(N - 1) == int(has[:, N - 1].sum())
+        mgr.close()
+
+
+def test_initial_covariances_beyond_the_host_mirror(models):
+    """getP0 is served from a host mirror of the distinct P0 matrices of a model, up to 4096 of them; a manager fed more than that
+    stops mirroring and says so (Q and R, per class, are always there)."""
+    import ctypes as C
+    from target_estimation_amd import capi
+    m = models["uniform_velocity"]
+    N = 5000
+    P0 = np.tile(m["P"], (N, 1, 1)) * (1.0 + 1e-3 * np.arange(N))[:, None, None]      # 5000 distinct matrices
+    ids = np.arange(N, dtype=np.uint32)
+    p0 = np.tile([0, 0, 0, 0, 0, 0, 1.0], (N, 1))
+    mgr = te.TargetManager()
+    mgr.init_batch(ids[:100], 0.004, 0.0, p0[:100], type=m["model"], Q=m["Q"], R=m["R"], P0=P0[:100])
+    np.testing.assert_array_equal(mgr.getModelMatrices(57)[2], P0[57])               # within the mirror
+    mgr.init_batch(ids[100:], 0.004, 0.0, p0[100:], type=m["model"], Q=m["Q"], R=m["R"], P0=P0[100:])
+    assert mgr.getModelMatrices(57) is None                                            # P0 no longer kept ...
+    Q = np.empty((6, 6)); R = np.empty((3, 3))
+    ok = capi.lib().target_manager_get_model_matrices(mgr.handle, 4321, Q.ctypes.data_as(capi.c_double_p), R.ctypes.data_as(capi.c_double_p), None)
+    assert ok                                                                          # ... Q and R still are
+    np.testing.assert_array_equal(Q, m["Q"]); np.testing.assert_array_equal(R, m["R"])
+    x, P = mgr.get_state_batch(ids[4990:4992])
+    np.testing.assert_allclose(P[0], P0[4990], rtol=1e-15)                             # the filter itself got every P0
+    del C
+    mgr.close()
+
+
+def test_log_of_an_fp32_manager(tmp_path, models):
+    name = "uniform_acceleration"
+    m = models[name]
+    p0, meas = synth_stream(name, 3, 4, seed=2)
+    ids = np.array([1, 2, 3], dtype=np.uint32)
+    mgr = te.TargetManager(model_path(name), dtype="f32")
+    mgr.init_batch(ids, 0.004, 0.0, p0)
+    orc = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], p0, 0.004, dtype="f32")
+    mgr.set_log_directory(tmp_path)
+    for s in range(4):
+        mgr.update_batch(ids, 0.004, meas[s])
+        orc.step(0.004, meas[s])
+        mgr.log()
+    np.testing.assert_allclose(_rows(tmp_path / "est_pose_2", 7)[-1], orc.pose()[1], rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(_rows(tmp_path / "meas_pose_2", 7)[-1], orc.measured_pose()[1], rtol=6e-6)
+    Po = orc.state()[1][1].ravel()
+    np.testing.assert_allclose(_rows(tmp_path / "covariance_2", 81)[-1], Po, rtol=2e-3, atol=2e-3 * np.abs(Po).max())
+    mgr.close()
