@@ -100,7 +100,7 @@ struct StepArgs {
   long live_ring;
   long live_first;
   unsigned live_spin_limit;
-  int live_flags;   // experiments (TE_LIVE_FLAGS): 2 = plain measurement loads
+  int live_flags;   // (reserved for experiments, TE_LIVE_FLAGS; unused)
   // live_pose (or null): SoA [7][live_pose_ld] doubles in device memory that receives the estimated pose of every target after
   // every tick (what the reference's node publishes every tick, src/target_manager_ros.cpp:78-87), written THROUGH the caches
   // before the tick's progress word, so that a copy engine that reads it after `done` reached the tick sees that tick's poses
@@ -134,7 +134,7 @@ __device__ __forceinline__ bool live_wait_tick(const long long* mirror, long lon
 // The relay wavefront: host doorbell -> device mirror, worker progress -> host.  Leaves when a stop was requested (by the
 // host, or by itself after `limit` polls without news from the host) and every worker has served the posted ticks.
 __device__ __forceinline__ void live_relay(const long long* posted, long long* mirror, const int* progress, int* done, long waves,
-                                           unsigned limit, int lane) {
+                                           unsigned limit, int lane, int flags) {
   long long last = 0;
   int last_done = 0;
   unsigned idle = 0;   // consecutive rounds in which nothing happened: no news from the host, no progress of the workers
@@ -149,8 +149,11 @@ __device__ __forceinline__ void live_relay(const long long* posted, long long* m
       int p[32];
 #pragma unroll
       for (int k = 0; k < 32; ++k) {
-        const long w = w0 + (long)k * 64 + lane;
-        p[k] = w < waves ? __hip_atomic_load(&progress[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
+        // every load unconditional (an index past the end re-reads the last word: harmless for a minimum): a load behind a
+        // per-element condition gets a branch and an `s_waitcnt vmcnt(0)` of its own -- 25 serial round trips again
+        long w = w0 + (long)k * 64 + lane;
+        w = w < waves ? w : waves - 1;
+        p[k] = __hip_atomic_load(&progress[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
 #pragma unroll
       for (int k = 0; k < 32; ++k) mn = p[k] < mn ? p[k] : mn;
@@ -184,7 +187,13 @@ __device__ __forceinline__ void live_relay(const long long* posted, long long* m
       if ((long long)mn >= (last & kLiveCount)) break;   // every worker has served the posted ticks and is leaving
       if (idle >= limit) break;                          // (a worker that never ran: nothing more to wait for)
     }
-    __builtin_amdgcn_s_sleep(2);
+    // The workers' progress stores and this wavefront's scan meet in the same lines: scanned back to back, a busy session's
+    // ticks get slower (10^5 UA fp32: 1.2 -> 2.0 us per tick).  While the workers are more than a tick behind what is posted
+    // nobody is waiting for the next completion word, so the scan can take its time; with at most one tick outstanding (a paced
+    // stream) it stays tight.
+    const long long behind = (last & kLiveCount) - (long long)mn;
+    if ((flags & 8) || behind > 1) __builtin_amdgcn_s_sleep(96);
+    else __builtin_amdgcn_s_sleep(2);
   }
 }
 

@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR>())) k
   if constexpr (LIVE) {   // the workgroup behind the last worker is the relay between the host's words and the device's
     const long workers = (a.n + TPW - 1) / TPW;
     if (wg == workers) {
-      live_relay(a.live_posted, a.live_mirror, a.live_progress, a.live_done, workers, a.live_spin_limit, lane);
+      live_relay(a.live_posted, a.live_mirror, a.live_progress, a.live_done, workers, a.live_spin_limit, lane, a.live_flags);
       return;
     }
   }
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR>())) k
   if (valid && meas_t != nullptr) {
 #pragma unroll
     for (int c = 0; c < MW; ++c) {
-      if constexpr (LIVE) ymeas[c] = (a.live_flags & 2) ? meas_t[(long)c * a.meas_ld + entry] : load_meas_live(&meas_t[(long)c * a.meas_ld + entry]);
+      if constexpr (LIVE) ymeas[c] = load_meas_live(&meas_t[(long)c * a.meas_ld + entry]);   // (no per-load run-time choice here: it would get a branch and a wait per word)
       else ymeas[c] = load_meas(&meas_t[(long)c * a.meas_ld + entry], a.nt_meas);
     }
     if (has_t != nullptr) {

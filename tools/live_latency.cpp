@@ -54,9 +54,14 @@ int main(int argc, char** argv) {
   posted += burst;
   if (target_batch_live_wait(b, posted, 20.0) != 0) return 10;
   const double b2b = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / burst;
+  const auto t1 = std::chrono::steady_clock::now();
+  target_batch_live_post(b, burst);           // the same number of ticks behind ONE doorbell: the device alone
+  posted += burst;
+  if (target_batch_live_wait(b, posted, 20.0) != 0) return 11;
+  const double one = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count() / burst;
   const long served = target_batch_live_stop(b);
-  std::printf("%ld targets %s: paced mean %.2f us, median %.2f, min %.2f, p99 %.2f; back to back %.2f us per tick; %ld ticks served\n", n,
-              f32 ? "f32" : "f64", mean / paced, us[(size_t)paced / 2], us[0], us[(size_t)(paced * 0.99)], b2b, served);
+  std::printf("%ld targets %s: paced mean %.2f us, median %.2f, min %.2f, p99 %.2f; back to back %.2f us per tick; one doorbell for %ld ticks %.2f us per tick; %ld ticks served\n", n,
+              f32 ? "f32" : "f64", mean / paced, us[(size_t)paced / 2], us[0], us[(size_t)(paced * 0.99)], b2b, burst, one, served);
   target_manager_delete(m);
   (void)hipFree(ring_dev);
   return served == posted ? 0 : 1;
