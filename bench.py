@@ -166,7 +166,10 @@ def block_ticks(steps):
 
 class Clock:
     """R repetitions of exactly K steps, each bracketed by barrier + synchronize on both sides (the contract's timed
-    region, repeated); HIP events on the launch stream give the device time of the same regions."""
+    region, repeated); HIP events on the launch stream give the device time of the same regions.  A rank's wall time runs
+    from the opening barrier + synchronize to the synchronize that ends ITS K steps; the closing barrier follows the stamp
+    and the MAX over ranks is what is reported (with the stamp behind the barrier every rank would report the same time plus
+    the barrier's own latency, which is not part of the K steps and which N = 1 does not pay)."""
 
     def __init__(self, torch, dist, device=True):
         self.torch, self.dist, self.device = torch, dist, device   # device=False: the dry run (protocol only, no GPU)
@@ -194,8 +197,9 @@ class Clock:
             run_steps(steps)
             if self.device:
                 e1.record()
-            self.fence()
-            wall.append(time.perf_counter() - t0)
+                torch.cuda.synchronize()
+            wall.append(time.perf_counter() - t0)   # this rank's K steps, complete on its device; the MAX over ranks is taken below
+            self.fence()                            # closing barrier + synchronize: no rank starts the next region early
             dev.append(e0.elapsed_time(e1) if self.device else wall[-1] * 1e3)
 
         def over_ranks(values, op):
