@@ -292,11 +292,46 @@ void Batch::upload_slots(const int* slots, long n) {
 long Batch::append(long count, const unsigned* ids, double t0, const double* P0, bool per_target_P0,
                    const double* p0, const double* v0, const double* a0, int cls, const int* cls_of, const int* P0_index,
                    long P0_count) {
+  const int N = ops_->L.n;
+  // ONE target (the reference's TargetManager::init, called target by target): queued.  The slot, its id and the host
+  // mirrors exist at once; the record is written by the next flush() -- one init launch for a whole run of creations with
+  // the same (t0, P0, class) instead of three copies, a launch and a synchronisation each (28 us -> 0.3 us per target).
+  if (count == 1 && !per_target_P0 && !cls_of && !P0_index && v0 && a0 && n_ < cap_ && !live_.active) {
+    InitQueue& q = initq_;
+    if (!q.ids.empty() && (t0 != q.t0 || cls != q.cls || std::memcmp(P0, q.P0.data(), sizeof(double) * (size_t)N * N) != 0)) flush_inits();
+    if (q.ids.empty()) { q.t0 = t0; q.cls = cls; q.P0.assign(P0, P0 + (size_t)N * N); q.first = n_; }
+    q.ids.push_back(ids[0]);
+    q.p0.insert(q.p0.end(), p0, p0 + 7);
+    q.v0.insert(q.v0.end(), v0, v0 + 6);
+    q.a0.insert(q.a0.end(), a0, a0 + 6);
+    cache_valid_ = false;   // the getter table is laid out by n_
+    if (p0_kept_) {
+      slot_p0_.resize((size_t)n_, 0);
+      const int r = intern_p0(P0);
+      if (p0_kept_) slot_p0_.push_back(r);
+    }
+    slot_ids_.push_back(ids[0]);
+    return n_++;
+  }
   touch();
   if (count <= 0) return n_;
-  const long first = n_;
+  return append_now(n_, count, ids, t0, P0, per_target_P0, p0, v0, a0, cls, cls_of, P0_index, P0_count, true);
+}
+
+void Batch::flush_inits() {
+  InitQueue& q = initq_;
+  if (q.ids.empty()) return;
+  InitQueue w;
+  w.ids.swap(q.ids); w.p0.swap(q.p0); w.v0.swap(q.v0); w.a0.swap(q.a0); w.P0.swap(q.P0);   // (append_now synchronises: nothing re-enters)
+  append_now(q.first, (long)w.ids.size(), w.ids.data(), q.t0, w.P0.data(), false, w.p0.data(), w.v0.data(), w.a0.data(), q.cls, nullptr, nullptr, 0, false);
+}
+
+// The device side of append (and, with `bookkeeping`, the host side of a multi-target append): records first .. first + count.
+long Batch::append_now(long first, long count, const unsigned* ids, double t0, const double* P0, bool per_target_P0,
+                       const double* p0, const double* v0, const double* a0, int cls, const int* cls_of, const int* P0_index,
+                       long P0_count, bool bookkeeping) {
   const int N = ops_->L.n;
-  reserve(n_ + count);
+  reserve(first + count);
   stage_reserve((cls_of || P0_index) ? 3 * count : count);   // slot list (+ per-entry class and P0 indices)
   std::vector<int> slots((size_t)count);
   for (long i = 0; i < count; ++i) slots[(size_t)i] = (int)(first + i);
@@ -332,7 +367,7 @@ long Batch::append(long count, const unsigned* ids, double t0, const double* P0,
     init_measured_rows_kernel<<<(unsigned)((count * 7 + 255) / 256), 256, 0, stream_>>>(d_lastmeas_, first, count);
     TE_HIP_CHECK(hipGetLastError());
   }
-  if (p0_kept_) {   // host mirror of the initial covariances (initial_covariance)
+  if (p0_kept_ && bookkeeping) {   // host mirror of the initial covariances (initial_covariance)
     slot_p0_.resize((size_t)first, 0);
     if (P0_index) {
       std::vector<int> row((size_t)P0_count);
@@ -346,8 +381,10 @@ long Batch::append(long count, const unsigned* ids, double t0, const double* P0,
     }
   }
   TE_HIP_CHECK(hipStreamSynchronize(stream_));  // host staging arrays may be pageable
-  slot_ids_.insert(slot_ids_.end(), ids, ids + count);
-  n_ += count;
+  if (bookkeeping) {
+    slot_ids_.insert(slot_ids_.end(), ids, ids + count);
+    n_ += count;
+  }
   return first;
 }
 
@@ -762,7 +799,7 @@ void Batch::pin_reserve(long k) {
 
 void Batch::cache_reserve(long n) {
   if (n <= cache_cap_) return;
-  const long want = std::max<long>(std::max<long>(n, 64), std::min<long>(cache_cap_ * 2, kCacheMax));
+  const long want = std::max<long>(std::max<long>(n, 64), std::min<long>(cache_cap_ * 2, n > kCacheMax ? kCacheBigMax : kCacheMax));
   TE_HIP_CHECK(hipStreamSynchronize(stream_));
   if (h_cache_) (void)hipHostFree(h_cache_);
   h_cache_ = nullptr; d_cache_ = nullptr; cache_cap_ = 0;
@@ -780,6 +817,7 @@ static bool spin_wait_enabled() {
 
 void Batch::flush() {
   if (live_.active) live_stop();   // the records in HBM are stale while a live kernel holds the state
+  flush_inits();                   // queued creations first: a queued step may be for one of them
   const long k = (long)pending_.size();
   if (!k) return;
   pin_reserve(k);
@@ -886,12 +924,14 @@ void Batch::outputs_dev(double* pose_dev, double* twist_dev, double* acc_dev, bo
 void Batch::outputs_one(long slot, double* pose, double* twist, double* acc, bool at_time, double t1) {
   flush();
   const int one = (int)slot;
-  if (at_time || n_ > kCacheMax) {
+  ++epoch_getters_;
+  const bool big = n_ > kCacheMax;
+  if (at_time || n_ > kCacheBigMax || (big && !cache_valid_ && !big_sweeps_ && epoch_getters_ <= kBigDirect)) {
     outputs(&one, 1, pose, twist, acc, at_time, t1);
     return;
   }
-  // small batch (the reference's scale): a host-resident table of every slot's outputs, written by the
-  // kernels themselves; filled once, then kept current by flush()
+  // a host-resident table of every slot's outputs, written by the kernels themselves; filled once, then kept current by
+  // flush().  Small batches (the reference's scale) always; large ones when the caller sweeps them (batch_store.hpp)
   if (!cache_valid_) {
     cache_reserve(n_);
     OutArgs a;

@@ -272,6 +272,11 @@ class Batch {
   unsigned long graph_clock_ = 0;   // recorded sequences are evicted least-recently-used first (64 kept)
   hipStream_t cap_stream_ = nullptr;
   void drop_graphs();
+  // queue of one-target creations (append with count == 1): consecutive ones with the same (t0, P0, class) become one init launch
+  struct InitQueue { std::vector<unsigned> ids; std::vector<double> p0, v0, a0, P0; double t0 = 0.0; int cls = 0; long first = 0; } initq_;
+  void flush_inits();
+  long append_now(long first, long count, const unsigned* ids, double t0, const double* P0, bool per_target_P0, const double* p0,
+                  const double* v0, const double* a0, int cls, const int* cls_of, const int* P0_index, long P0_count, bool bookkeeping);
   // queue of one-target steps (reference C ABI) and the cache that serves the one-target getters
   struct Pending { int slot; unsigned char has; double dt; double meas[7]; };
   std::vector<Pending> pending_;
@@ -285,7 +290,15 @@ class Batch {
   char* h_pin_ = nullptr;                    // idx int[cap] | dt double[cap] | meas T[7][cap] | has uchar[cap]
   char* d_pin_ = nullptr;                    // the same memory as the device sees it
   long pin_cap_ = 0;
-  static constexpr long kCacheMax = 16384;   // batches up to this size keep every slot's outputs on the host
+  // The getter table.  Batches up to kCacheMax build it at the first one-target getter after a change.  A larger batch
+  // (up to kCacheBigMax) builds it only for a caller that really sweeps it target by target: the first kBigDirect getters
+  // after a change are served one by one (a launch and a copy each), the next one builds the table; a batch that was swept
+  // last time builds it at once, one that was not (a dense step followed by a single getter) goes back to single reads.
+  static constexpr long kCacheMax = 16384;
+  static constexpr long kCacheBigMax = 1L << 22;   // 19 doubles per target: 640 MB of pinned host memory at most
+  static constexpr int kBigDirect = 64;
+  long epoch_getters_ = 0;                   // one-target getters since the last change
+  bool big_sweeps_ = false;                  // the last epoch of this (large) batch was a sweep
   void cache_reserve(long n);
   double* h_cache_ = nullptr;                // [n][7] pose | [n][6] twist | [n][6] acceleration
   double* d_cache_ = nullptr;
@@ -295,7 +308,12 @@ class Batch {
   int* d_done_ = nullptr;
   unsigned done_seq_ = 0;
   void wait_done(int seq);                   // spin on *h_done_ == seq, falling back to hipStreamSynchronize
-  void touch() { flush(); cache_valid_ = false; }   // call before anything that changes state
+  void touch() {                             // call before anything that changes state
+    flush();
+    cache_valid_ = false;
+    if (epoch_getters_ > 0) big_sweeps_ = epoch_getters_ > kBigDirect;   // (changes with no getter in between keep the verdict)
+    epoch_getters_ = 0;
+  }
   struct Live {
     bool active = false;
     long long* h_posted = nullptr;   // host-mapped: [0] the doorbell (count | stop bit), [8] (as int) the relay's "done" word

@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR>())) k
 #pragma unroll
   for (int i = 0; i < NLIN; ++i) {
     T xs[LB], Pb[LB][LB], Qb[LB][LB];
-    T r_meas;
+    T r_meas = T(0);   // (every path assigns it; the per-class branches hide that from the compiler)
 #pragma unroll
     for (int b = 0; b < LB; ++b) {
       xs[b] = XW_(i + STRIDE * b);

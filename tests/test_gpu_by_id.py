@@ -114,3 +114,46 @@ def test_random_order_by_id_calls_resolved_on_device(models, dtype):
     t = TOL[dtype]
     assert (np.abs(x - xo[keep_rows]) - (t["x_atol"] + t["x_rtol"] * np.abs(xo[keep_rows]))).max() <= 0
     mgr.close()
+
+
+def test_one_target_getters_sweeping_a_large_batch(models):
+    """A reference-style caller at a scale the reference never reaches: 20 000 targets (more than the always-on getter
+    table holds) read back ONE BY ONE through the ten-symbol getters.  The first reads after a change are single launches,
+    a sweep switches to the host table (csrc/batch_store.hpp kBigDirect), one-target updates keep it current, a dense tick
+    drops it -- at every stage each target's pose / twist / acceleration are the batched getter's, bit for bit."""
+    name, dtype, N, dt = "uniform_acceleration", "f64", 20000, 0.004
+    m = models[name]
+    p0, meas = synth_stream(name, N, 4, seed=77)
+    ids = (np.arange(N, dtype=np.uint32) * 3 + 1)
+    mgr = te.TargetManager(dtype=dtype)
+    assert mgr.init_batch(ids, dt, 0.0, p0, type=m["model"], Q=m["Q"], R=m["R"], P0=m["P"]) == N
+    b = mgr.batches()[0]
+
+    def sweep(which):
+        pose, twist, acc, found = mgr.get_est_batch(ids)
+        assert found.all()
+        for k in which:
+            i = int(ids[k])
+            for got, want in ((mgr.getTargetPose(i), pose[k]), (mgr.getTargetTwist(i), twist[k]), (mgr.getTargetAcceleration(i), acc[k])):
+                assert got[0]
+                np.testing.assert_array_equal(got[1], want)
+
+    mgr.update_batch(ids, dt, meas[0])
+    sweep(range(0, N, 997))                       # a handful: single reads
+    sweep(range(N))                               # a sweep: the table
+    touched = np.arange(5, N, 401)
+    for k in touched:                             # one-target updates behind a current table (the queue, then one indexed launch)
+        mgr.update(int(ids[k]), dt, meas[1][k])
+    sweep(list(touched) + list(range(0, N, 1999)))
+    b.step(dt, torch.from_numpy(np.ascontiguousarray(meas[2].T)).cuda())      # a dense tick: the table is stale
+    sweep([0, N - 1])                             # (the batch swept last time: the table is rebuilt at once)
+    sweep(range(N))
+    b.step(dt, None)
+    sweep([17])                                   # a single read after a change ...
+    b.step(dt, None)
+    sweep([N - 2, 3])                             # ... and the batch is back to single reads
+    # and the oracle on the targets that took the extra one-target step
+    sub = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], p0[touched], dt, dtype=dtype)
+    sub.step(dt, meas[0][touched]); sub.step(dt, meas[1][touched]); sub.step(dt, meas[2][touched]); sub.step(dt, None); sub.step(dt, None)
+    _cmp(mgr, ids[touched], sub, dtype, "one-target updates of a large batch")
+    mgr.close()

@@ -591,3 +591,64 @@ def test_a_failure_inside_stream_capture_leaves_no_capture_behind():
     blob = open(_build.DEFAULT_LIB, "rb").read()
     assert b"TE_TEST_FAIL_IN_CAPTURE" not in blob and b"TE_TEST_FAIL_IN_CAPTURE" in open(lib, "rb").read()
     del ctypes
+
+
+@pytest.mark.parametrize("name,dtype", [("uniform_acceleration", "f64"), ("angular_velocities", "f32")])
+def test_one_by_one_creations_equal_a_batched_creation(models, name, dtype, capfd):
+    """TargetManager::init target by target (the reference's only way to create targets; queued here, one init launch per run
+    of creations) with everything a caller may put between two creations -- a step of the target just created, a getter, an
+    erase, a change of t0, a second model -- against a manager built by init_batch and stepped by update_batch: the same
+    bits, the same clocks and counters."""
+    m = models[name]
+    other = models["uniform_velocity"]
+    N, dt = 3000, 0.004
+    p0, meas = synth_stream(name, N, 2, seed=5)
+    rng = np.random.default_rng(8)
+    v0 = rng.uniform(-0.3, 0.3, (N, 6)) * np.array([1, 1, 1, 0.1, 0.1, 0.1])
+    a0 = rng.uniform(-0.1, 0.1, (N, 6)) * 0.1
+    ids = (rng.permutation(100000)[:N]).astype(np.uint32)
+    t0 = np.where(np.arange(N) < 1000, 0.0, np.where(np.arange(N) < 2200, 1.5, 0.25))     # runs of creations at three clocks
+    stepped = np.arange(N) % 37 == 5
+    a = te.TargetManager(dtype=dtype)
+    for i in range(N):
+        a.init(int(ids[i]), dt, float(t0[i]), p0[i], v0[i], a0[i], type=m["model"], Q=m["Q"], R=m["R"], P0=m["P"])
+        if stepped[i]:
+            a.update(int(ids[i]), dt, meas[0][i])            # a queued step of a queued creation
+        if i % 501 == 17:
+            assert a.getNumberMeasurements(int(ids[i])) == int(stepped[i])      # a read in the middle of a run
+        if i == 1500:                                         # a second model in between (its own batch, its own queue)
+            a.init(900001, dt, 0.0, p0[0], np.zeros(6), np.zeros(6), type=other["model"], Q=other["Q"], R=other["R"], P0=other["P"])
+        if i == 2000:                                         # an erase in the middle of a run, and the id again
+            assert a.erase(int(ids[1990]))
+            a.init(int(ids[1990]), dt, float(t0[1990]), p0[1990], v0[1990], a0[1990], type=m["model"], Q=m["Q"], R=m["R"], P0=m["P"])
+            if stepped[1990]:
+                a.update(int(ids[1990]), dt, meas[0][1990])
+    a.init(int(ids[7]), dt, 0.0, p0[8], v0[8], a0[8], type=m["model"], Q=m["Q"], R=m["R"], P0=m["P"])   # an existing id: the reference's message, nothing changes
+    assert "already exists" in capfd.readouterr().out
+    b = te.TargetManager(dtype=dtype)
+    for tt in (0.0, 1.5, 0.25):
+        sel = t0 == tt
+        assert b.init_batch(ids[sel], dt, tt, p0[sel], v0[sel], a0[sel], type=m["model"], Q=m["Q"], R=m["R"], P0=m["P"]) == sel.sum()
+    b.update_batch(ids[stepped], dt, meas[0][stepped])
+    assert a.size() == N + 1 and b.size() == N
+    for mgr in (a, b):
+        mgr.update_batch(ids, dt, meas[1])
+    xa, Pa = a.get_state_batch(ids)
+    xb, Pb = b.get_state_batch(ids)
+    np.testing.assert_array_equal(xa, xb)
+    np.testing.assert_array_equal(Pa, Pb)
+    pa, pb = a.get_est_batch(ids), b.get_est_batch(ids)
+    for u, w in zip(pa, pb):
+        np.testing.assert_array_equal(u, w)
+    for i in list(range(0, N, 211)) + [1990]:
+        assert a.getTime(int(ids[i])) == b.getTime(int(ids[i])) == pytest.approx(t0[i] + dt * (1 + stepped[i]), abs=1e-12)
+        assert a.getNumberMeasurements(int(ids[i])) == 1 + int(stepped[i])
+    orc = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], p0, dt, 0.0, v0, a0, dtype=dtype)
+    for i in np.nonzero(stepped)[0]:
+        _one(orc, int(i), dt, meas[0][i])
+    orc.step(dt, meas[1])
+    t = TOL[dtype]
+    xo, Po = orc.state()
+    assert (np.abs(xa - xo) <= t["x_atol"] + t["x_rtol"] * np.abs(xo)).all()
+    assert (np.abs(Pa - Po) / np.abs(Po).max(axis=(1, 2), keepdims=True)).max() <= t["P_rel"]
+    a.close(); b.close()

@@ -309,7 +309,7 @@ def test_a_busy_session_is_not_an_idle_one(models):
     """The idle limit counts rounds in which NOTHING happens.  A burst that takes longer to serve than the limit (the host is
     silent because it waits for it) must not end the session: later doorbells are still served."""
     mgr, b, st, ids, p0, live = _setup(models, "uniform_acceleration", "f32", 100_000, 8, 0.004, 3)
-    b.live_start(0.004, st["meas"], max_ticks=1 << 20, idle_limit_s=0.01)      # 10 ms
+    b.live_start(0.004, st["meas"], max_ticks=1 << 20, idle_limit_s=0.02)      # 20 ms
     b.live_post(40_000)                                                         # ~50 ms of work in one doorbell
     assert b.live_wait(40_000, 10.0)
     b.live_post(7)
