@@ -299,6 +299,10 @@ class Batch {
   static constexpr int kBigDirect = 64;
   long epoch_getters_ = 0;                   // one-target getters since the last change
   bool big_sweeps_ = false;                  // the last epoch of this (large) batch was a sweep
+  static constexpr int kCounterDirect = 4;   // single reads of a measurement counter before all of them are copied to the host
+  std::vector<int> h_nm_;
+  bool nm_valid_ = false;
+  int nm_reads_ = 0;
   void cache_reserve(long n);
   double* h_cache_ = nullptr;                // [n][7] pose | [n][6] twist | [n][6] acceleration
   double* d_cache_ = nullptr;
@@ -311,6 +315,7 @@ class Batch {
   void touch() {                             // call before anything that changes state
     flush();
     cache_valid_ = false;
+    nm_valid_ = false; nm_reads_ = 0;
     if (epoch_getters_ > 0) big_sweeps_ = epoch_getters_ > kBigDirect;   // (changes with no getter in between keep the verdict)
     epoch_getters_ = 0;
   }

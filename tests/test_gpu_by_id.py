@@ -145,6 +145,11 @@ def test_one_target_getters_sweeping_a_large_batch(models):
     for k in touched:                             # one-target updates behind a current table (the queue, then one indexed launch)
         mgr.update(int(ids[k]), dt, meas[1][k])
     sweep(list(touched) + list(range(0, N, 1999)))
+    want_nm = np.ones(N, dtype=int); want_nm[touched] += 1
+    assert [mgr.getNumberMeasurements(int(i)) for i in ids] == list(want_nm)       # the counters, target by target (host copy after a few reads)
+    mgr.update(int(ids[3]), dt, meas[1][3]); want_nm[3] += 1                       # a step drops that copy
+    assert [mgr.getNumberMeasurements(int(i)) for i in ids[:40]] == list(want_nm[:40])
+    touched = np.append(touched, 3)
     b.step(dt, torch.from_numpy(np.ascontiguousarray(meas[2].T)).cuda())      # a dense tick: the table is stale
     sweep([0, N - 1])                             # (the batch swept last time: the table is rebuilt at once)
     sweep(range(N))
@@ -152,6 +157,7 @@ def test_one_target_getters_sweeping_a_large_batch(models):
     sweep([17])                                   # a single read after a change ...
     b.step(dt, None)
     sweep([N - 2, 3])                             # ... and the batch is back to single reads
+    assert [mgr.getNumberMeasurements(int(i)) for i in ids[::13]] == list(want_nm[::13] + 1)     # the dense tick with measurements counted once more
     # and the oracle on the targets that took the extra one-target step
     sub = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], p0[touched], dt, dtype=dtype)
     sub.step(dt, meas[0][touched]); sub.step(dt, meas[1][touched]); sub.step(dt, meas[2][touched]); sub.step(dt, None); sub.step(dt, None)
