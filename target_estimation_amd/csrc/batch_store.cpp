@@ -591,7 +591,8 @@ void Batch::step_fused(long n_ticks, double dt, const void* meas_base, long tick
 
 // device block of a live session: [one mirror word per kLiveGroup wavefronts, 128 bytes apart][progress words]
 static size_t live_mirror_bytes(long waves) { return (size_t)((waves + kLiveGroup - 1) / kLiveGroup) * kLiveMirrorStride * sizeof(long long); }
-static size_t live_block_bytes(long waves) { return (live_mirror_bytes(waves) + sizeof(int) * (size_t)waves + 15) / 16 * 16; }
+static long live_progress_words(long waves) { return (waves + kLiveScan - 1) / kLiveScan * kLiveScan; }   // whole relay scans
+static size_t live_block_bytes(long waves) { return (live_mirror_bytes(waves) + sizeof(int) * (size_t)live_progress_words(waves) + 15) / 16 * 16; }
 
 void Batch::live_start(double dt, const void* meas_ring, long tick_stride, long ld, const unsigned char* has_ring, long has_stride,
                        long ring_ticks, long first_entry, long max_ticks, double idle_limit_s, const double* q_origin, double q_radius,
@@ -636,6 +637,9 @@ void Batch::live_start(double dt, const void* meas_ring, long tick_stride, long 
   TE_HIP_CHECK(hipEventRecord(live_.ready, stream_));
   TE_HIP_CHECK(hipStreamWaitEvent(live_.stream, live_.ready, 0));
   TE_HIP_CHECK(hipMemsetAsync(live_.d_block, 0, live_block_bytes(waves), live_.stream));   // mirrors + progress: zero before EVERY launch
+  if (live_progress_words(waves) > waves)   // the padding of the progress words: INT_MAX, neutral in the relay's minimum
+    TE_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(live_.d_block + live_mirror_bytes(waves) + sizeof(int) * (size_t)waves), 0x7fffffff,
+                                   (size_t)(live_progress_words(waves) - waves), live_.stream));
   StepParams p = base_params();
   p.meas = meas_ring; p.meas_ld = ld; p.has_meas = has_ring; p.dt = dt;
   p.n_ticks = (int)max_ticks; p.tick_stride = tick_stride; p.has_stride = has_stride;

@@ -145,15 +145,15 @@ __device__ __forceinline__ void live_relay(const long long* posted, long long* m
     long long v = 0;
     if (lane == 0) v = __hip_atomic_load(posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     int mn = 0x7fffffff;
-    for (long w0 = 0; w0 < waves; w0 += 64 * 32) {
+    for (long w0 = 0; w0 < waves; w0 += kLiveScan) {
       int p[32];
 #pragma unroll
       for (int k = 0; k < 32; ++k) {
-        // every load unconditional (an index past the end re-reads the last word: harmless for a minimum): a load behind a
-        // per-element condition gets a branch and an `s_waitcnt vmcnt(0)` of its own -- 25 serial round trips again
-        long w = w0 + (long)k * 64 + lane;
-        w = w < waves ? w : waves - 1;
-        p[k] = __hip_atomic_load(&progress[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // every load unconditional: a load behind a per-element condition gets a branch and an `s_waitcnt vmcnt(0)` of its own
+        // -- 25 serial round trips again.  The array is padded to whole rounds (kLiveScan words) with INT_MAX, which a minimum
+        // ignores, so the 32 addresses are ONE base plus constants (clamped indices cost an address pair each, and those
+        // registers -- this wavefront shares the kernel with the workers -- cost every batch its resident capacity).
+        p[k] = __hip_atomic_load(&progress[w0 + (long)k * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
 #pragma unroll
       for (int k = 0; k < 32; ++k) mn = p[k] < mn ? p[k] : mn;

@@ -216,6 +216,7 @@ constexpr long long kLiveStop = (long long)(1ull << 63);    // sign bit: "stop o
 constexpr long long kLiveCount = (long long)(~(1ull << 63));
 constexpr int kLiveGroup = 32;           // worker wavefronts that share one copy of the relay's mirror word
 constexpr int kLiveMirrorStride = 16;    // long longs between copies (128 bytes: a line of its own each)
+constexpr long kLiveScan = 64 * 32;      // progress words the relay reads per round trip (32 per lane); the array is padded to whole scans with INT_MAX
 
 struct LayoutInfo {
   int n, m, g, layout, tpw, lpt, record_words;
