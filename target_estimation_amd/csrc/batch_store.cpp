@@ -604,7 +604,7 @@ void Batch::live_start(double dt, const void* meas_ring, long tick_stride, long 
     throw std::invalid_argument("target_estimation_amd: live_start: bad measurement ring");
   if (max_ticks > 0x7fffffffL) throw std::invalid_argument("target_estimation_amd: live_start: at most 2^31 - 1 ticks per session");
   if (n_classes_ > 1) throw std::runtime_error("target_estimation_amd: live mode serves batches with one (Q, R) class");
-  const long cap = ops_->live_capacity ? ops_->live_capacity() : 0;
+  const long cap = ops_->live_capacity ? ops_->live_capacity((q_delta_dev || live_.pose_out) ? 1 : 0) : 0;
   if (cap <= 0) throw std::runtime_error("target_estimation_amd: live mode needs the axis-separable layout with packed groups");
   const long waves = (n_ + ops_->L.tpw - 1) / ops_->L.tpw;
   if (waves > cap)

@@ -103,7 +103,9 @@ class Batch {
   bool live_wait(long tick, double timeout_s) const;
   long live_stop();            // returns the ticks served
   bool live_active() const { return live_.active; }
-  long live_capacity_targets() const { return ops_->live_capacity ? ops_->live_capacity() * ops_->L.tpw : 0; }
+  // targets a session can hold; with_outputs: one with the per-tick query or pose output (a larger kernel: fewer)
+  long live_capacity_targets(bool with_outputs = false) const { return ops_->live_capacity ? ops_->live_capacity(with_outputs ? 1 : 0) * ops_->L.tpw : 0; }
+  bool live_pose_output_set() const { return live_.pose_out != nullptr; }
   // One tick over the listed slots, host inputs (meas rows follow the order of `slots`).
   void step_indexed(const int* slots, long n, double dt, const double* meas_aos, const unsigned char* has);
   // The same with everything already on the device: idx_dev [n] = slot of entry e or a negative number (entry skipped);

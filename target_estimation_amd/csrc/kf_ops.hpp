@@ -57,7 +57,7 @@ struct Ops {
   bool fused_query;  // step() honours StepParams::q_delta
   void (*step)(const StepParams&, hipStream_t);
   // wavefronts of the live kernel the device can hold at once (0: this (model, precision, layout) has no live kernel)
-  long (*live_capacity)();
+  long (*live_capacity)(int with_outputs);   // resident wavefronts of the plain / the query-and-pose-output variant
   void (*init)(const InitArgs&, hipStream_t);
   void (*get_state)(char* rec, const int* idx, long n, double* x, double* P, hipStream_t);
   void (*set_state)(char* rec, const int* idx, long n, const double* x, const double* P, const double* uw, hipStream_t);

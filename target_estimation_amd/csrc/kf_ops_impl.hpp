@@ -16,13 +16,14 @@ struct OpsImpl {
   using C = Cfg<M, T, G, LAYOUT>;
 
   static constexpr bool kHasLive = LAYOUT == LAYOUT_SEPARABLE_PACKED;
-  static long live_capacity() {
+  static long live_capacity(int with_outputs) {   // with_outputs: the variant with the per-tick query / pose output (LIVE == 2)
     if constexpr (kHasLive) {
       int per_cu = 0, dev = 0;
       hipDeviceProp_t prop;
       if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kf_step_sep_kernel<M, T, LAYOUT, false, true, false, false, true>, 64, 0) != hipSuccess)
-        return 0;
+      const void* kernel = with_outputs ? (const void*)kf_step_sep_kernel<M, T, LAYOUT, false, true, false, false, 2>
+                                        : (const void*)kf_step_sep_kernel<M, T, LAYOUT, false, true, false, false, 1>;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess) return 0;
       // the occupancy query can over-report by one block per CU (cdna_hip_programming.md, residency): keep one in hand
       return (long)(per_cu > 1 ? per_cu - 1 : 1) * (long)prop.multiProcessorCount;
     } else {
@@ -49,7 +50,10 @@ struct OpsImpl {
           throw std::runtime_error("target_estimation_amd: a live launch is a dense launch of a one-class batch over a measurement ring");
         const long waves_live = (p.n + C::TPW - 1) / C::TPW;
         // + 1: the relay wavefront (kf_step.hpp live_relay)
-        hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, false, true, false, false, true>), dim3((unsigned)waves_live + 1), dim3(64), 0, s, a);
+        if (p.q_delta || p.live_pose)
+          hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, false, true, false, false, 2>), dim3((unsigned)waves_live + 1), dim3(64), 0, s, a);
+        else
+          hipLaunchKernelGGL((kf_step_sep_kernel<M, T, LAYOUT, false, true, false, false, 1>), dim3((unsigned)waves_live + 1), dim3(64), 0, s, a);
         return;
       } else {
         throw std::runtime_error("target_estimation_amd: live mode needs the axis-separable layout with packed groups (the automatic choice for the shipped models)");

@@ -87,9 +87,10 @@ template <class M, typename T, int LAYOUT, bool PERQR>
 constexpr int sep_min_waves() { return (PERQR && M::TYPE == ANGULAR_RATES && sizeof(T) == 8 && LAYOUT == LAYOUT_SEPARABLE_PACKED) ? 3 : 1; }
 
 // LIVE: a resident launch (StepArgs::live_*): the tick loop of FUSED with a wait for the host's doorbell in front of every tick
-// and a progress word behind it.  Same arithmetic per tick, same results as single ticks.
+// and a progress word behind it (1), optionally with the per-tick sphere query and pose output (2: more registers, so fewer
+// resident targets).  Same arithmetic per tick, same results as single ticks.
 // AB: an A -> B tick (StepArgs::rec_out), its own instantiation (see kf_step_kernel).
-template <class M, typename T, int LAYOUT, bool INDEXED, bool FUSED = false, bool QUERY = false, bool PERQR = false, bool LIVE = false, bool AB = false>
+template <class M, typename T, int LAYOUT, bool INDEXED, bool FUSED = false, bool QUERY = false, bool PERQR = false, int LIVE = 0, bool AB = false>
 __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR>())) kf_step_sep_kernel(const StepArgs<T> a) {
   static_assert(!AB || (!INDEXED && !FUSED && !QUERY && !LIVE), "A -> B ticks are dense single-tick launches without the fused query");
   static_assert(!(QUERY && (INDEXED || FUSED)), "the fused query is for dense single-tick launches");
@@ -489,9 +490,11 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR>())) k
     }
   }
 
-  if constexpr (LIVE) {
-    // the own-time sphere query of every target after every tick (BASELINE configs[4]), on the posterior still in registers;
-    // a run-time choice here: the resident kernel exists once per (model, precision)
+  if constexpr (LIVE == 2) {
+    // the own-time sphere query of every target after every tick (BASELINE configs[4]), on the posterior still in registers,
+    // and / or the tick's poses for a consumer outside the kernel.  Run-time choices inside the LIVE == 2 variant only: the
+    // query's fp64 quartic and the pose derivation cost 30 - 60 registers, i.e. resident capacity, which a plain session
+    // (LIVE == 1) keeps.
     if (a.q_delta != nullptr && valid) {
       T xq[N];
 #pragma unroll
@@ -511,6 +514,8 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR>())) k
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the rows have left before the progress word says so
     }
+  }
+  if constexpr (LIVE) {
     // tick `tick` is done (state in registers): a word in device memory for the relay
     if (lane == 0) __hip_atomic_store(&a.live_progress[wave_id], tick + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }

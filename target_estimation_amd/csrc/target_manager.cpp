@@ -1223,7 +1223,7 @@ void TargetManager::liveStartAll(double dt, const Batch::SeqSpec* specs, long n_
   for (size_t b = 0; b < nb; ++b) {
     if (batches_[b]->size() == 0) throw std::runtime_error("target_estimation_amd: liveStartAll: an empty batch");
     if (specs[b].ring_ticks <= 0) throw std::invalid_argument("target_estimation_amd: liveStartAll: every batch needs a measurement ring");
-    const long cap = batches_[b]->live_capacity_targets();
+    const long cap = batches_[b]->live_capacity_targets(query || batches_[b]->live_pose_output_set());
     if (cap <= 0) throw std::runtime_error("target_estimation_amd: live mode needs the axis-separable layout with packed groups (batch " + std::to_string(b) + ")");
     share += (double)(batches_[b]->size() + batches_[b]->layout().tpw) / (double)cap;   // + one tile for the relay wavefront
   }

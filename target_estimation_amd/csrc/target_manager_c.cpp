@@ -445,7 +445,7 @@ long target_batch_live_stop(target_batch_c* b) {
   return guarded_value<long>("target_batch_live_stop", -1L, [&] { BatchLock lk(B(b)); return B(b)->live_stop(); });
 }
 long target_batch_live_capacity(target_batch_c* b) {
-  return guarded_value<long>("target_batch_live_capacity", -1L, [&] { return B(b)->live_capacity_targets(); });
+  return guarded_value<long>("target_batch_live_capacity", -1L, [&] { return B(b)->live_capacity_targets(B(b)->live_pose_output_set()); });
 }
 
 int target_manager_live_start_all(target_manager_c* m, double dt, const target_batch_sequence_c* per_batch, long n_batches, long first_entry,
