@@ -28,6 +28,7 @@ import math
 import os
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -1025,6 +1026,8 @@ def main():
     ap.add_argument("--gather", action="store_true", help="(kept for compatibility: the gather report is on by default)")
     ap.add_argument("--no-gather", action="store_true", help="skip the gather report (it runs AFTER the line has been printed when N > 1)")
     ap.add_argument("--gather-deadline", type=float, default=60.0, help="seconds the pose gather may take before the run gives up (exit 3)")
+    ap.add_argument("--post-deadline", type=float, default=1500.0, help="seconds the extras and the gather may take AFTER the line has been "
+                    "printed before every rank gives up on them (exit 0)")
     ap.add_argument("--side-file", default="", help="where everything that is not the line goes (default bench_extra.json next to bench.py)")
     ap.add_argument("--launch-mode", default="auto", choices=["auto", "python", "sequence", "graph", "fused", "live"],
                     help="how the per-tick launches are enqueued (always one kernel launch per batch per tick, except 'fused')")
@@ -1125,10 +1128,26 @@ def main():
     if rank == 0:
         emit(compact_line(out))
         write_side(args, dict(side, line=out))
+    # Everything below is optional and the line is out: a rank that falls out of step in an extra (an exception between two
+    # barriers on one rank only) must not leave the job hanging at the others' barrier.  After --post-deadline seconds every
+    # rank says so and leaves (exit 0: the record stands; the side file says what is missing).
+    extras = []
+
+    def post_deadline():
+        print("bench.py: rank %d: extras / gather did not finish within %.0f s; leaving (the line was printed)" % (rank, args.post_deadline),
+              file=sys.stderr, flush=True)
+        if rank == 0:
+            try:
+                write_side(args, dict(side, line=out, extra=list(extras), extras_incomplete=True))
+            except Exception:
+                pass
+        os._exit(0)
+    post_timer = threading.Timer(args.post_deadline, post_deadline)
+    post_timer.daemon = True
+    post_timer.start()
     # Extra workloads.  One GPU: the full list.  Several GPUs: one 10^6-targets-per-GPU workload per YAML motion model plus
     # the configs' per-GPU shares, every rank in lockstep (same barriers, max over ranks).
     extra_names = [e for e in (args.extra if world == 1 else args.extra_multi).split(",") if e]
-    extras = []
     for name in extra_names:
         if name == args.workload:
             continue
@@ -1204,6 +1223,7 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    post_timer.cancel()
     if rank == 0:
         write_side(args, dict(side, line=out))
         print(json.dumps(dict(side, line=out)), file=sys.stderr)
