@@ -12,7 +12,7 @@ tail -c 2500 $OUT/bench_line.json
 echo "== kernel trace" | tee -a $OUT/progress.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --side-file $OUT/bench_extra_trace.json > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 echo "trace rc=$?" | tee -a $OUT/progress.txt
-python3 tools/summarize_trace.py $OUT/trace $OUT/bench_trace.json > $OUT/bench_default_rocprofv3.txt 2>> $OUT/progress.txt
+python3 tools/summarize_trace.py $OUT/trace $OUT/bench_trace.json $OUT/bench_extra_trace.json > $OUT/bench_default_rocprofv3.txt 2>> $OUT/progress.txt
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/bench_default_kernel_stats.csv \;
 rm -rf $OUT/trace
 echo "== all-in-one PMC pass (once)" | tee -a $OUT/progress.txt

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """rocprofv3 --kernel-trace CSV -> one line per (kernel, grid): calls, avg / min / max duration.
-usage: tools/summarize_trace.py <dir with *kernel_trace.csv> [bench.json]   (prints to stdout)"""
+usage: tools/summarize_trace.py <dir with *kernel_trace.csv> [bench line file [bench side file]]   (prints to stdout)"""
 import csv
 import glob
 import json
@@ -25,7 +25,8 @@ def main():
             g = int(r.get("Grid_Size_X") or r.get("Grid_Size") or 0)
             groups[(short(r["Kernel_Name"]), g)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     print("# rocprofv3 --kernel-trace --stats summary; template arguments of kf_step_sep_kernel: <model, precision, layout (2 = separable,")
-    print("# 3 = separable + packed), INDEXED, FUSED, QUERY, PERQR>, of kf_step_kernel: <model, precision, lanes per target, layout (0 = full, 1 = packed), ...>")
+    print("# 3 = separable + packed), INDEXED, FUSED, QUERY, PERQR, LIVE (1 = resident, 2 = resident with per-tick query / pose output), AB>, of kf_step_kernel:")
+    print("# <model, precision, lanes per target, layout (0 = full, 1 = packed), INDEXED, FUSED, QUERY, PERQR, AB>")
     print("%-78s %9s %6s %10s %10s %10s" % ("kernel", "grid", "calls", "avg_us", "min_us", "max_us"))
     rows = sorted(groups.items(), key=lambda kv: -sum(kv[1]))
     for (k, g), durs in rows:
@@ -38,7 +39,10 @@ def main():
         print("# bench line of the same process: value %.4g %s, ms_per_step %.4f, roofline.kernel %s avg_launch_ms %.4f (HIP events) -- compare with the"
               % (b["value"], b["unit"], b["ms_per_step"], b["roofline"]["kernel"], b["roofline"]["avg_launch_ms"]))
         print("# rocprofv3 average of that kernel at grid %d above" % (-(-b["roofline"]["units_per_launch"] // 256) * 256))
-        for k in b["roofline"]["kernels"]:
+        kernels = b["roofline"].get("kernels")
+        if kernels is None and len(sys.argv) > 3:          # the per-kernel table lives in the side file (bench.py --side-file)
+            kernels = json.load(open(sys.argv[3]))["roofline"]["kernels"]
+        for k in kernels or []:
             print("#   %-44s units %8d  avg_launch_ms (events) %.4f" % (k["kernel"], k["units_per_launch"], k["avg_launch_ms"]))
 
 
