@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Long-horizon parity of the layouts against the oracle: worst |dx| and |dP|/max|P| after many ticks.
-usage: python tools/drift.py [steps]"""
+usage: python tests/extended/drift.py [steps]   (on the GPU box; test infrastructure: it uses the oracle)"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch

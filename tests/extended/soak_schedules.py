@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak run of tests/test_gpu_edge_cases.py::test_randomised_schedule_against_oracle over many seeds (GPU box).
-usage: python tools/soak.py <number of seeds>   (6 random schedules per seed)"""
+usage: python tests/extended/soak_schedules.py <number of seeds>   (from the repo root; test infrastructure: it uses the oracle)   (6 random schedules per seed)"""
 import sys
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import conftest, oracle

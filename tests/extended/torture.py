@@ -2,7 +2,7 @@
 """Parity under extreme inputs (GPU box): positions up to 1e5, P0 scaled by 1e-4..1e4, tick lengths from 1e-4 to 0.5 s,
 random masks, unnormalised quaternions of either sign, body rates up to 40 rad/s (unwrapped angles reach hundreds
 of radians).  The EKF model is kept away from pitch = +-pi/2, where the reference's Euler-angle Jacobians are
-singular (1/cos^2 pitch) and any two implementations diverge.  usage: python tools/torture.py"""
+singular (1/cos^2 pitch) and any two implementations diverge.  usage: python tests/extended/torture.py   (from the repo root; test infrastructure: it uses the oracle)"""
 import sys
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np, torch
