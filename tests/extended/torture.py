@@ -8,7 +8,7 @@ sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np, torch
 import oracle, conftest
 import target_estimation_amd as te
-from target_estimation_amd.streams import qtran_matrix
+from oracle import np_twin as tw
 rng = np.random.default_rng(123)
 worst = {}
 for trial in range(24):
@@ -35,7 +35,7 @@ for trial in range(24):
         dt = float(rng.choice([1e-4, 0.004, 0.05] if ekf else [1e-4, 0.004, 0.05, 0.5]))
         t += dt
         pos = pos + v * dt
-        M = qtran_matrix(dt, torch.from_numpy(omega)).numpy()
+        M = np.stack([tw.qtran(dt, omega[i]) for i in range(N)])
         q = np.einsum("nij,nj->ni", M, q); q /= np.linalg.norm(q, axis=1, keepdims=True)
         qm = q * rng.uniform(0.5, 2.0, (N, 1)) * (1 if rng.random() < 0.5 else -1)    # unnormalised, either sign
         meas = np.concatenate([pos + rng.normal(0, 0.01, (N, 3)), qm], 1)
