@@ -1117,6 +1117,12 @@ def main():
             bw = copy_bandwidth(torch)
             side["roofline"]["measured_copy_gbs"] = bw["copy"]
             side["roofline"]["measured_triad_gbs"] = bw["triad"]
+            # fractions of the box's own streaming rates next to the fraction of the 8 TB/s nominal peak
+            side["roofline"]["tick"]["frac_of_measured_copy"] = side["roofline"]["tick"]["achieved"] / bw["copy"]
+            side["roofline"]["tick"]["frac_of_measured_triad"] = side["roofline"]["tick"]["achieved"] / bw["triad"]
+            for k in side["roofline"].get("kernels", []):
+                k["frac_of_measured_copy"] = k["achieved_gbs"] / bw["copy"]
+                k["frac_of_measured_triad"] = k["achieved_gbs"] / bw["triad"]
         except Exception as exc:
             side["roofline"]["copy_bandwidth_error"] = str(exc)[:200]
     maps_checkpoint(args.workload)
