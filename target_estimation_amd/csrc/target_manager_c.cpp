@@ -536,7 +536,7 @@ target_ingest_c* target_ingest_new(target_manager_c* manager, int type, const do
 }
 
 void target_ingest_delete(target_ingest_c* ingest) {
-  if (ingest) delete (te::MeasurementIngest*)ingest;
+  if (ingest) guarded("target_ingest_delete", [&] { delete (te::MeasurementIngest*)ingest; });
 }
 
 void target_ingest_set_expiration_time(target_ingest_c* ingest, double seconds) {
@@ -577,7 +577,9 @@ target_intersection_solver_c* target_intersection_solver_new(target_manager_c* m
   guarded("target_intersection_solver_new", [&] { sv = new te::IntersectionSolver(M(manager), filters_length); });
   return (target_intersection_solver_c*)sv;
 }
-void target_intersection_solver_delete(target_intersection_solver_c* solver) { delete (te::IntersectionSolver*)solver; }
+void target_intersection_solver_delete(target_intersection_solver_c* solver) {
+  if (solver) guarded("target_intersection_solver_delete", [&] { delete (te::IntersectionSolver*)solver; });
+}
 double target_intersection_solver_get_time_with_sphere(target_intersection_solver_c* solver, unsigned int id, double t1,
                                                         const double* origin, double radius) {
   return guarded_value<double>("target_intersection_solver_get_time_with_sphere", -1.0, [&] {
