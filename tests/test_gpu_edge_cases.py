@@ -652,3 +652,85 @@ def test_one_by_one_creations_equal_a_batched_creation(models, name, dtype, capf
     assert (np.abs(xa - xo) <= t["x_atol"] + t["x_rtol"] * np.abs(xo)).all()
     assert (np.abs(Pa - Po) / np.abs(Po).max(axis=(1, 2), keepdims=True)).max() <= t["P_rel"]
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_random_one_target_call_sequences_against_oracle(models, seed, capfd):
+    """Fuzz of the reference's own call pattern -- everything one target at a time, in any order: create (two models, three
+    clocks, so that the creation queue breaks into runs), step with and without a measurement, read pose / twist / counter /
+    time, erase and re-create.  Each id has its own oracle target; every read is compared when it happens, the state at the
+    end.  (Queued creations, queued steps, the getter table, the counter mirror and swap-with-last erase all meet here.)"""
+    rng = np.random.default_rng(seed)
+    names = ["uniform_velocity", "angular_rates"]
+    dtype = "f64"
+    t = TOL[dtype]
+    mgr = te.TargetManager(dtype=dtype)
+    pool = list(range(100, 100 + 260))
+    alive = {}            # id -> (oracle target, model name, time, n_meas)
+    dt = 0.004
+    big = 300 if seed == 13 else 0                       # one run with enough targets for the batch to outgrow a wavefront of queue entries
+    for step in range(2600 + big * 4):
+        op = rng.random()
+        if op < (0.30 if len(alive) < 200 + big else 0.05) or not alive:
+            cand = [i for i in pool if i not in alive] or [int(rng.integers(1000, 100000))]
+            i = int(rng.choice(cand))
+            if i in alive:
+                continue
+            name = names[int(rng.random() < 0.35)]
+            m = models[name]
+            t0 = float(rng.choice([0.0, 0.5, 2.0]))
+            p0 = np.concatenate([rng.uniform(-5, 5, 3), [0, 0, 0, 1.0]])
+            v0 = rng.uniform(-0.5, 0.5, 6) * np.array([1, 1, 1, 0.1, 0.1, 0.1])
+            a0 = rng.uniform(-0.1, 0.1, 6) * 0.1
+            mgr.init(i, dt, t0, p0, v0, a0, type=m["model"], Q=m["Q"], R=m["R"], P0=m["P"])
+            alive[i] = [oracle.OracleTarget(m["model"], m["Q"], m["R"], m["P"], p0, dt, t0, v0, a0, dtype=dtype), name, t0, 0]
+            if len(alive) > 200 + big:
+                pool.append(i)
+        elif op < 0.72:
+            i = int(rng.choice(list(alive)))
+            o = alive[i]
+            d = float(rng.choice([0.004, 0.001, 0.02]))
+            if rng.random() < 0.8:
+                pose = o[0].pose()[0]
+                meas = np.concatenate([pose[:3] + rng.normal(0, 0.01, 3), pose[3:]])
+                mgr.update(i, d, meas); o[0].add_measurement(d, meas); o[3] += 1
+            else:
+                mgr.update(i, d); o[0].update(d)
+            o[2] += d
+        elif op < 0.92:
+            i = int(rng.choice(list(alive)))
+            o = alive[i]
+            kind = int(rng.integers(4))
+            if kind == 0:
+                ok, got = mgr.getTargetPose(i)
+                assert ok and np.abs(got - o[0].pose()[0]).max() <= t["out_atol"], (step, i)
+            elif kind == 1:
+                ok, got = mgr.getTargetTwist(i)
+                assert ok and np.abs(got - o[0].twist()[0]).max() <= t["out_atol"], (step, i)
+            elif kind == 2:
+                assert mgr.getNumberMeasurements(i) == o[3], (step, i)
+            else:
+                assert mgr.getTime(i) == pytest.approx(o[2], abs=1e-9), (step, i)
+        elif op < 0.97:
+            i = int(rng.choice(list(alive)))
+            assert mgr.erase(i)
+            del alive[i]
+            assert not mgr.getTargetPose(i)[0]
+        else:                                            # a sweep of reads over everything alive (the table path for every size)
+            for i in list(alive)[:: max(1, len(alive) // 40)]:
+                ok, got = mgr.getTargetPose(i)
+                assert ok and np.abs(got - alive[i][0].pose()[0]).max() <= t["out_atol"], (step, i)
+    assert mgr.size() == len(alive)
+    assert sorted(mgr.getAvailableTargets()) == sorted(alive)
+    ids = np.array(sorted(alive), dtype=np.uint32)
+    for name in names:
+        sel = np.array([i for i in ids if alive[int(i)][1] == name], dtype=np.uint32)
+        if not len(sel):
+            continue
+        x, P = mgr.get_state_batch(sel)
+        for k, i in enumerate(sel):
+            xo, Po = alive[int(i)][0].state()
+            assert (np.abs(x[k] - xo[0]) <= t["x_atol"] + t["x_rtol"] * np.abs(xo[0])).all(), (name, int(i))
+            assert (np.abs(P[k] - Po[0]) / np.abs(Po[0]).max()).max() <= t["P_rel"], (name, int(i))
+    capfd.readouterr()
+    mgr.close()
