@@ -255,8 +255,10 @@ int target_batch_step_fused(target_batch_c* b, long n_ticks, double dt, const vo
  * Results equal those of single ticks bit for bit.  While a session is open the records in HBM are stale: any other call on
  * the batch (steps, getters, erase, init) ends the session first.  Needs the automatic layout of the shipped models
  * (axis-separable, packed groups), one (Q, R) class and a batch small enough to be fully resident: ..._live_capacity targets
- * (on an MI355X, by model: 1.8 to 5.1 * 10^5 fp32 targets, 3.1 to 3.8 * 10^5 fp64 linear-model targets, 4.9 * 10^4 for the fp64
- * angular models; a session with the per-tick query or pose output runs a larger kernel: 1.8 to 4.4 * 10^5 fp32).  Posting faster than the device serves is fine: a wavefront that is behind catches up
+ * (on an MI355X: 3.1 * 10^5 targets for the linear models, 1.8 to 2.5 * 10^5 fp32 / 4.9 * 10^4 fp64 for the angular ones; a session
+ * with the per-tick query or pose output runs a larger kernel: 1.8 to 3.1 * 10^5 fp32).  ..._live_start returns once the resident kernel
+ * is known to run (its last workgroup says so) and fails after 2 s otherwise; the kernel runs on a high-priority stream of the
+ * library's own, so that no stream of the caller shares its hardware queue (work queued behind an endless kernel waits for its end).  Posting faster than the device serves is fine: a wavefront that is behind catches up
  * without polling. */
 int target_batch_live_start(target_batch_c* b, double dt, const void* meas_ring_dev, long tick_stride, long ld,
                             const unsigned char* has_ring_dev, long has_stride, long ring_ticks, long first_entry, long max_ticks,

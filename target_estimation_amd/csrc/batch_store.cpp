@@ -170,6 +170,7 @@ StepParams Batch::base_params() const {
 
 Batch::~Batch() {
   if (live_.active) { try { live_stop(); } catch (...) {} }
+  if (live_.zombie && live_.stream) (void)hipStreamSynchronize(live_.stream);   // (told to stop: it ends as soon as it starts)
   (void)hipStreamSynchronize(stream_);
   drop_graphs();
   if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
@@ -604,7 +605,8 @@ void Batch::live_start(double dt, const void* meas_ring, long tick_stride, long 
     throw std::invalid_argument("target_estimation_amd: live_start: bad measurement ring");
   if (max_ticks > 0x7fffffffL) throw std::invalid_argument("target_estimation_amd: live_start: at most 2^31 - 1 ticks per session");
   if (n_classes_ > 1) throw std::runtime_error("target_estimation_amd: live mode serves batches with one (Q, R) class");
-  const long cap = ops_->live_capacity ? ops_->live_capacity((q_delta_dev || live_.pose_out) ? 1 : 0) : 0;
+  long cap = ops_->live_capacity ? ops_->live_capacity((q_delta_dev || live_.pose_out) ? 1 : 0) : 0;
+  if (const char* e = std::getenv("TE_LIVE_CAPACITY_WAVES")) { if (cap > 0 && std::atol(e) > 0) cap = std::atol(e); }   // experiments only (tools/live_capacity.py --probe)
   if (cap <= 0) throw std::runtime_error("target_estimation_amd: live mode needs the axis-separable layout with packed groups");
   const long waves = (n_ + ops_->L.tpw - 1) / ops_->L.tpw;
   if (waves > cap)
@@ -627,12 +629,22 @@ void Batch::live_start(double dt, const void* meas_ring, long tick_stride, long 
     live_.cap_waves = waves;
   }
   __atomic_store_n(live_.h_posted, 0LL, __ATOMIC_RELAXED);
-  __atomic_store_n(live_.h_done, 0, __ATOMIC_RELAXED);
+  __atomic_store_n(live_.h_done, -1, __ATOMIC_RELAXED);   // the relay's first store makes it 0: "running"
+  __atomic_store_n(live_.h_done + 2, 0, __ATOMIC_RELAXED);    // the relay's last store makes it 1: "ended"
   __atomic_thread_fence(__ATOMIC_SEQ_CST);
   // The resident kernel gets a stream of its own (non-blocking), ordered behind everything already queued on the batch's
   // stream: nothing the caller queues later on that stream -- for this batch's siblings in the manager, say -- waits for the
   // session, and two batches of one manager can be resident together.
-  if (!live_.stream) TE_HIP_CHECK(hipStreamCreateWithFlags(&live_.stream, hipStreamNonBlocking));
+  if (!live_.stream) {
+    // A stream of its own PRIORITY class: the runtime multiplexes the streams of one priority over a few hardware queues, and
+    // a stream that lands in the resident kernel's queue waits until the session ends (a ring refill on "another stream" took
+    // 1.6 - 17 s, i.e. the idle limit, whenever that happened; with GPU_MAX_HW_QUEUES=1 always).  Queues are not shared across
+    // priorities, so the resident kernel gets the high-priority class to itself (callers' streams are normal priority unless
+    // they ask otherwise).
+    int least = 0, greatest = 0;
+    TE_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    TE_HIP_CHECK(hipStreamCreateWithPriority(&live_.stream, hipStreamNonBlocking, greatest));
+  }
   if (!live_.ready) TE_HIP_CHECK(hipEventCreateWithFlags(&live_.ready, hipEventDisableTiming));
   TE_HIP_CHECK(hipEventRecord(live_.ready, stream_));
   TE_HIP_CHECK(hipStreamWaitEvent(live_.stream, live_.ready, 0));
@@ -660,8 +672,26 @@ void Batch::live_start(double dt, const void* meas_ring, long tick_stride, long 
   }
   ops_->step(p, live_.stream);   // (the measured-pose rows are not kept during a live session: see measured_pose.hpp)
   TE_HIP_CHECK(hipGetLastError());
-  live_.active = true; live_.waves = waves; live_.posted = 0; live_.max_ticks = max_ticks; live_.dt = dt;
+  live_.waves = waves; live_.posted = 0; live_.max_ticks = max_ticks; live_.dt = dt;
   live_.all_measured = has_ring == nullptr;
+  // The session exists once its LAST workgroup (the relay) says so: then every worker holds its wave slot.  A kernel that is
+  // still queued after two seconds is not going to run next to whatever is ahead of it (its stream shares a hardware queue with
+  // another endless kernel -- more live batches than GPU_MAX_HW_QUEUES, or a caller's own high-priority stream -- or the device
+  // cannot hold the whole grid): told to stop as soon as it starts, and reported, instead of a session that never serves a tick.
+  const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(kLiveStartTimeoutS);
+  for (unsigned spins = 0; __atomic_load_n(live_.h_done, __ATOMIC_ACQUIRE) < 0; ++spins) {
+    __builtin_ia32_pause();
+    if ((spins & 1023u) != 1023u) continue;
+    const hipError_t q = hipStreamQuery(live_.stream);
+    if (q != hipErrorNotReady && q != hipSuccess) TE_HIP_CHECK(q);
+    if (std::chrono::steady_clock::now() < t_end) continue;
+    __atomic_store_n(live_.h_posted, kLiveStop, __ATOMIC_RELEASE);
+    live_.zombie = true;   // flush() waits for it before anything touches the records
+    throw std::runtime_error("target_estimation_amd: live mode: the resident kernel did not start within " + std::to_string(kLiveStartTimeoutS) +
+                             " s (its stream shares a hardware queue with another endless kernel -- more live batches than GPU_MAX_HW_QUEUES, or a "
+                             "high-priority stream of the caller -- or the device is busy)");
+  }
+  live_.active = true;
 }
 
 void Batch::live_set_pose_output(double* pose_soa_dev, long ld) {
@@ -680,7 +710,7 @@ void Batch::live_post(long n_ticks) {
 
 long Batch::live_done() const {
   if (!live_.active) return 0;
-  return (long)__atomic_load_n(live_.h_done, __ATOMIC_ACQUIRE);
+  return std::max(0L, (long)__atomic_load_n(live_.h_done, __ATOMIC_ACQUIRE));
 }
 
 bool Batch::live_wait(long tick, double timeout_s) const {
@@ -699,7 +729,7 @@ long Batch::live_stop() {
   TE_HIP_CHECK(hipStreamSynchronize(live_.stream));   // bounded: every wavefront drains the posted ticks, then sees the stop bit
   // the relay's last word: the ticks EVERY wavefront served.  The host's stop, or the relay's own after a silent host, reaches
   // all workers through one device word, so they all stop at the same tick.
-  const long mn = (long)__atomic_load_n(live_.h_done, __ATOMIC_ACQUIRE);
+  const long mn = std::max(0L, (long)__atomic_load_n(live_.h_done, __ATOMIC_ACQUIRE));
   t_acc_ += live_.dt * (double)mn;
   if (live_.all_measured) nm_acc_ += mn;
   if (mn != live_.posted)
@@ -821,6 +851,10 @@ static bool spin_wait_enabled() {
 }
 
 void Batch::flush() {
+  if (live_.zombie) {              // a resident kernel that never started in time: told to stop, it leaves the records as they are
+    live_.zombie = false;
+    TE_HIP_CHECK(hipStreamSynchronize(live_.stream));
+  }
   if (live_.active) live_stop();   // the records in HBM are stale while a live kernel holds the state
   flush_inits();                   // queued creations first: a queued step may be for one of them
   const long k = (long)pending_.size();

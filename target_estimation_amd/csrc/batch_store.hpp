@@ -106,6 +106,7 @@ class Batch {
   // targets a session can hold; with_outputs: one with the per-tick query or pose output (a larger kernel: fewer)
   long live_capacity_targets(bool with_outputs = false) const { return ops_->live_capacity ? ops_->live_capacity(with_outputs ? 1 : 0) * ops_->L.tpw : 0; }
   bool live_pose_output_set() const { return live_.pose_out != nullptr; }
+  bool live_running() const { return live_.active && __atomic_load_n(live_.h_done + 2, __ATOMIC_ACQUIRE) == 0; }   // the relay has not left (its last store)
   // One tick over the listed slots, host inputs (meas rows follow the order of `slots`).
   void step_indexed(const int* slots, long n, double dt, const double* meas_aos, const unsigned char* has);
   // The same with everything already on the device: idx_dev [n] = slot of entry e or a negative number (entry skipped);
@@ -321,8 +322,10 @@ class Batch {
     if (epoch_getters_ > 0) big_sweeps_ = epoch_getters_ > kBigDirect;   // (changes with no getter in between keep the verdict)
     epoch_getters_ = 0;
   }
+  static constexpr double kLiveStartTimeoutS = 2.0;
   struct Live {
     bool active = false;
+    bool zombie = false;             // launched, never seen running, told to stop: synchronise its stream before touching records
     long long* h_posted = nullptr;   // host-mapped: [0] the doorbell (count | stop bit), [8] (as int) the relay's "done" word
     long long* d_posted = nullptr;   // the same block as the device sees it
     int* h_done = nullptr;

@@ -24,7 +24,12 @@ struct OpsImpl {
       const void* kernel = with_outputs ? (const void*)kf_step_sep_kernel<M, T, LAYOUT, false, true, false, false, 2>
                                         : (const void*)kf_step_sep_kernel<M, T, LAYOUT, false, true, false, false, 1>;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess) return 0;
-      // the occupancy query can over-report by one block per CU (cdna_hip_programming.md, residency): keep one in hand
+      // Measured on an MI355X with the relay's start word (tools/live_capacity.py --probe, profiles/r03_live_capacity.txt): the
+      // largest grid that becomes resident is the query's figure for every kernel at up to 6 wavefronts per SIMD, but 28 per CU
+      // where the query says 32 (8 per SIMD).  And a device that full starves everybody else: with 22 or more resident
+      // wavefronts per CU (of 24 / 28) a device-to-device copy on another stream -- the caller's ring refill -- waited for the
+      // session to end, with 18.4 of 20 it took its usual 0.4 ms.  So: at most 5 per SIMD, and one block per CU in hand.
+      if (per_cu > 20) per_cu = 20;
       return (long)(per_cu > 1 ? per_cu - 1 : 1) * (long)prop.multiProcessorCount;
     } else {
       return 0;

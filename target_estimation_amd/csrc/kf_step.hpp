@@ -138,6 +138,9 @@ __device__ __forceinline__ void live_relay(const long long* posted, long long* m
   long long last = 0;
   int last_done = 0;
   unsigned idle = 0;   // consecutive rounds in which nothing happened: no news from the host, no progress of the workers
+  // "running": the host set the word to -1 before the launch.  This is the LAST workgroup of the grid and workgroups are dispatched
+  // in order, so the word also says that every worker has been given its wave slot (Batch::live_start waits for it).
+  if (lane == 0) __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   for (;;) {
     // One PCIe read per round, requested FIRST and consumed LAST: the scan of the workers' words below goes out behind it and
     // the round costs the longer of the two round trips, not their sum.  The scan keeps up to 32 independent loads in flight per
@@ -195,6 +198,9 @@ __device__ __forceinline__ void live_relay(const long long* posted, long long* m
     if ((flags & 8) || behind > 1) __builtin_amdgcn_s_sleep(96);
     else __builtin_amdgcn_s_sleep(2);
   }
+  // "ended" (done[2], host-mapped like done[0]): the host can tell a session that is over -- stopped, or given up on an idle
+  // host -- from one that is waiting, without asking the runtime about the stream
+  if (lane == 0) __hip_atomic_store(done + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // measurement word of a live tick: written by a copy engine or the host while the kernel runs, so it is read past the caches

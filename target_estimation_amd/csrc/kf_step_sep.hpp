@@ -83,15 +83,21 @@ __device__ __forceinline__ void sep_linear_axis(T* x, T (&P)[NB][NB], const T (&
 // Register budget the allocator must respect (wavefronts per SIMD it has to leave room for; 1 = unconstrained).  The
 // per-class angular_rates kernel in fp64 on packed group blocks sits two registers over the three-wave limit (170 of 168) when
 // left alone; held to it, it parks 12-24 B per lane in scratch (grouped classes 162 -> 156 us per 10^6-target tick).
-template <class M, typename T, int LAYOUT, bool PERQR>
-constexpr int sep_min_waves() { return (PERQR && M::TYPE == ANGULAR_RATES && sizeof(T) == 8 && LAYOUT == LAYOUT_SEPARABLE_PACKED) ? 3 : 1; }
+// (Resident kernels are never held to a register limit that makes them spill: a kernel with scratch is also limited by the
+// scratch wave slots the runtime has sized for the process, which the occupancy query does not see -- the angular_rates fp64
+// kernel, 6 registers over the two-wave limit, held to it: 114 000 targets started in a fresh process and did not in one that
+// had run other kernels before.)
+template <class M, typename T, int LAYOUT, bool PERQR, int LIVE = 0>
+constexpr int sep_min_waves() {
+  return (PERQR && M::TYPE == ANGULAR_RATES && sizeof(T) == 8 && LAYOUT == LAYOUT_SEPARABLE_PACKED) ? 3 : 1;
+}
 
 // LIVE: a resident launch (StepArgs::live_*): the tick loop of FUSED with a wait for the host's doorbell in front of every tick
 // and a progress word behind it (1), optionally with the per-tick sphere query and pose output (2: more registers, so fewer
 // resident targets).  Same arithmetic per tick, same results as single ticks.
 // AB: an A -> B tick (StepArgs::rec_out), its own instantiation (see kf_step_kernel).
 template <class M, typename T, int LAYOUT, bool INDEXED, bool FUSED = false, bool QUERY = false, bool PERQR = false, int LIVE = 0, bool AB = false>
-__global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR>())) kf_step_sep_kernel(const StepArgs<T> a) {
+__global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR, LIVE>())) kf_step_sep_kernel(const StepArgs<T> a) {
   static_assert(!AB || (!INDEXED && !FUSED && !QUERY && !LIVE), "A -> B ticks are dense single-tick launches without the fused query");
   static_assert(!(QUERY && (INDEXED || FUSED)), "the fused query is for dense single-tick launches");
   static_assert(!(PERQR && (FUSED || QUERY)), "per-class Q/R: single-tick launches without the fused query");

@@ -1237,6 +1237,12 @@ void TargetManager::liveStartAll(double dt, const Batch::SeqSpec* specs, long n_
                                     specs[started].has_stride, specs[started].ring_ticks, first_entry, max_ticks, idle_limit_s,
                                     query ? origin : nullptr, radius, query ? specs[started].delta_dev : nullptr,
                                     query ? specs[started].pose_dev : nullptr);
+    // side by side, or not at all: a kernel that could only start because an earlier one gave up (one hardware queue for all
+    // of them and an idle limit shorter than the start timeout) is not a session
+    for (size_t b = 0; b < nb; ++b)
+      if (!batches_[b]->live_running())
+        throw std::runtime_error("target_estimation_amd: liveStartAll: the batches' resident kernels do not run side by side (batch " + std::to_string(b) +
+                                 " has ended already: they share a hardware queue -- more live batches than GPU_MAX_HW_QUEUES?)");
   } catch (...) {
     for (size_t b = 0; b < started; ++b) { try { batches_[b]->live_stop(); } catch (...) {} }
     throw;

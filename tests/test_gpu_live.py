@@ -354,3 +354,111 @@ def test_per_tick_pose_output_of_a_live_session(models, name, dtype, N):
     assert b.live_done() == ticks and b.live_stop() == ticks
     b.live_set_pose_output(None)
     ref.close(); mgr.close()
+
+
+def test_ring_refill_on_another_stream_next_to_a_nearly_full_device(models):
+    """A session at 97 % of the capacity the library allows (uniform acceleration fp32: 18 of at most 19 resident wavefronts
+    per CU) must leave other streams alive: the device-to-device copy that refills the ring completes in its usual time and the
+    session goes on.  (Before the capacity was limited to 5 wavefronts per SIMD such a copy waited for the session to end.)"""
+    import time
+    name, dtype, dt = "uniform_acceleration", "f32", 0.004
+    probe = te.TargetManager(model_path(name), dtype=dtype)
+    p1 = np.zeros((64, 7)); p1[:, 6] = 1
+    probe.init_batch(np.arange(64, dtype=np.uint32), dt, 0.0, p1)
+    cap = probe.batches()[0].live_capacity
+    probe.close()
+    N = int(cap * 0.97) // 64 * 64
+    mgr, b, st, ids, p0, live = _setup(models, name, dtype, N, 32, dt, 17)
+    meas = st["meas"]
+    ring = meas[:16].clone()
+    torch.cuda.synchronize()
+    copy = torch.cuda.Stream()
+    b.live_start(dt, ring, max_ticks=32, idle_limit_s=3.0)
+    b.live_post(16)
+    assert b.live_wait(16, 5.0)
+    t0 = time.perf_counter()
+    with torch.cuda.stream(copy):
+        ring[:16].copy_(meas[16:32])
+    copy.synchronize()
+    assert time.perf_counter() - t0 < 0.5, "the refill waited for the resident kernel"
+    b.live_post(16)
+    assert b.live_wait(32, 5.0)
+    assert b.live_stop() == 32
+    with pytest.raises(RuntimeError, match="resident wavefronts"):                 # beyond the capacity: refused, not attempted
+        big = te.TargetManager(model_path(name), dtype=dtype)
+        q = np.zeros((cap + 64, 7)); q[:, 6] = 1
+        big.init_batch(np.arange(cap + 64, dtype=np.uint32), dt, 0.0, q)
+        try:
+            big.batches()[0].live_start(dt, torch.zeros((1, 7, cap + 64), dtype=torch.float32, device="cuda"), max_ticks=1)
+        finally:
+            big.close()
+    mgr.close()
+
+
+def _one_hardware_queue_case():
+    """Child process with GPU_MAX_HW_QUEUES=1: every stream of one priority shares ONE hardware queue.  (1) a single session
+    still lets a copy on another stream through (the resident kernel's stream has the high-priority class to itself);
+    (2) a two-batch session either runs (the runtime gave each high-priority stream its own queue) or, with both resident
+    kernels in one queue, is refused after the start timeout with a message; nothing hangs, the manager works afterwards."""
+    import os
+    import time
+    from conftest import MODEL_FILES
+    from target_estimation_amd.streams import make_stream
+    assert os.environ.get("GPU_MAX_HW_QUEUES") == "1"
+    models = {k: oracle.load_model_yaml(model_path(k)) for k in MODEL_FILES}
+    name, dtype, N, dt = "uniform_velocity", "f64", 10_000, 0.004
+    mgr, b, st, ids, p0, live = _setup(models, name, dtype, N, 32, dt, 5)
+    ring = st["meas"][:16].clone()
+    torch.cuda.synchronize()
+    copy = torch.cuda.Stream()
+    b.live_start(dt, ring, max_ticks=32, idle_limit_s=3.0)
+    b.live_post(16)
+    assert b.live_wait(16, 5.0)
+    t0 = time.perf_counter()
+    with torch.cuda.stream(copy):
+        ring[:16].copy_(st["meas"][16:32])
+    copy.synchronize()
+    assert time.perf_counter() - t0 < 0.5
+    b.live_post(16)
+    assert b.live_wait(32, 5.0) and b.live_stop() == 32
+    mgr.close()
+    # two batches
+    mgr = te.TargetManager(dtype=dtype)
+    mgr.set_stream(torch.cuda.Stream().cuda_stream)
+    rings = []
+    for k, nm in enumerate(("uniform_velocity", "uniform_acceleration")):
+        m = models[nm]
+        s2 = make_stream(MODELS[nm], 2000, 4, dt, 9 + k, dtype=dtype)
+        mgr.init_batch(np.arange(2000, dtype=np.uint32) + 10_000 * k, dt, 0.0, s2["p0"].cpu().numpy(), type=m["model"], Q=m["Q"], R=m["R"], P0=m["P"])
+        rings.append(s2["meas"])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    try:
+        mgr.live_start_all(dt, rings, max_ticks=4, idle_limit_s=1.0)
+        started = True
+    except RuntimeError as e:
+        started = False
+        assert "did not start within" in str(e) or "do not run side by side" in str(e), str(e)
+    assert time.perf_counter() - t0 < 30.0
+    if started:      # (this runtime gives every high-priority stream a queue of its own: then the session simply works)
+        mgr.live_post_all(4)
+        assert mgr.live_wait_all(4, 5.0) and mgr.live_stop_all() == 4
+        print("two resident kernels ran with GPU_MAX_HW_QUEUES=1")
+    else:
+        print("two resident kernels in one queue: refused")
+    x, P = mgr.get_state_batch(np.arange(5, dtype=np.uint32))                      # the manager is usable afterwards
+    assert np.isfinite(x).all()
+    for bb, r in zip(mgr.batches(), rings):                                        # and ordinary ticks still run
+        bb.step(dt, r[0])
+    torch.cuda.synchronize()
+    mgr.close()
+    print("one hardware queue ok")
+
+
+def test_sessions_with_one_hardware_queue_per_priority():
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="1", PYTHONPATH=os.pathsep.join([os.path.dirname(__file__), os.path.dirname(os.path.dirname(__file__))]))
+    p = subprocess.run([sys.executable, "-c", "import test_gpu_live as t; t._one_hardware_queue_case()"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "one hardware queue ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
