@@ -276,6 +276,9 @@ long target_batch_live_done(target_batch_c* b);
 int target_batch_live_wait(target_batch_c* b, long tick, double timeout_s);
 long target_batch_live_stop(target_batch_c* b);
 long target_batch_live_capacity(target_batch_c* b);
+/* 1 while the session's resident kernel is there (serving or waiting), 0 once it has left -- after ..._live_stop, or by itself after
+ * idle_limit_s without news (the records are back in HBM then; ..._live_stop still has to be called to close the session) */
+int target_batch_live_running(target_batch_c* b);
 /* n_ticks ticks of EVERY batch of the manager in one call (BASELINE.json configs[3]/[4]: several motion
  * models per GPU, optionally with the per-tick sphere query "fused on-GPU").  per_batch[i] describes
  * batch i (target_manager_get_batch order): measurements as for target_batch_step_sequence, plus the

@@ -134,6 +134,7 @@ SIGNATURES = {
     "target_batch_live_wait": (C.c_int, [C.c_void_p, C.c_long, C.c_double]),
     "target_batch_live_stop": (C.c_long, [C.c_void_p]),
     "target_batch_live_capacity": (C.c_long, [C.c_void_p]),
+    "target_batch_live_running": (C.c_int, [C.c_void_p]),
     "target_manager_live_start_all": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_double, C.c_int,
                                                 c_double_p, C.c_double]),
     "target_manager_live_post_all": (C.c_int, [C.c_void_p, C.c_long, C.c_int]),

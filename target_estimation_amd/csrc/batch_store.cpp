@@ -661,6 +661,11 @@ void Batch::live_start(double dt, const void* meas_ring, long tick_stride, long 
   // a poll is a PCIe round trip plus s_sleep: ~1-2 us; the limit is a count of polls
   const double polls = idle_limit_s > 0 ? idle_limit_s * 5e5 : 5e6;
   p.live_spin_limit = (unsigned)std::min(polls, 4.0e9);
+  {   // the relay measures the idle time on the device's constant-rate clock; the count above bounds the workers' own spins
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0)
+      p.live_idle_ticks = (unsigned long long)((idle_limit_s > 0 ? idle_limit_s : 10.0) * 1e3 * (double)khz);
+  }
   { const char* e = std::getenv("TE_LIVE_FLAGS"); p.live_flags = e ? std::atoi(e) : 0; }
   if (live_.pose_out) {
     if (live_.pose_ld < n_) throw std::invalid_argument("target_estimation_amd: live pose output: rows shorter than the batch (it grew since live_set_pose_output)");

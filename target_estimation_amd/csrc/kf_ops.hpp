@@ -46,6 +46,7 @@ struct StepParams {
   int* live_done = nullptr;
   long live_ring = 0, live_first = 0;
   unsigned live_spin_limit = 0;
+  unsigned long long live_idle_ticks = 0;
   int live_flags = 0;
   double* live_pose = nullptr;   // SoA [7][live_pose_ld] per-tick pose output of a live launch, or null
   long live_pose_ld = 0;

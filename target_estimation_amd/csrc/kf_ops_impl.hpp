@@ -48,7 +48,7 @@ struct OpsImpl {
     a.o_pose = p.o_pose; a.o_twist = p.o_twist; a.o_acc = p.o_acc; a.done_flag = p.done_flag; a.done_seq = p.done_seq;
     a.live_posted = p.live_posted; a.live_mirror = p.live_mirror; a.live_progress = p.live_progress; a.live_done = p.live_done;
     a.live_ring = p.live_ring; a.live_first = p.live_first;
-    a.live_spin_limit = p.live_spin_limit; a.live_flags = p.live_flags; a.live_pose = p.live_pose; a.live_pose_ld = p.live_pose_ld;
+    a.live_spin_limit = p.live_spin_limit; a.live_idle_ticks = p.live_idle_ticks; a.live_flags = p.live_flags; a.live_pose = p.live_pose; a.live_pose_ld = p.live_pose_ld;
     if (p.live_posted) {   // resident launch: one wavefront per workgroup, every workgroup resident (Batch::live_start checked the capacity)
       if constexpr (kHasLive) {
         if (p.idx || p.cls || p.rec_out || !p.live_progress || !p.live_mirror || !p.live_done || p.live_ring <= 0 || p.n_ticks < 1)

@@ -100,6 +100,7 @@ struct StepArgs {
   long live_ring;
   long live_first;
   unsigned live_spin_limit;
+  unsigned long long live_idle_ticks;   // the idle limit on the device's wall clock (0: count relay rounds instead, live_spin_limit)
   int live_flags;   // (reserved for experiments, TE_LIVE_FLAGS; unused)
   // live_pose (or null): SoA [7][live_pose_ld] doubles in device memory that receives the estimated pose of every target after
   // every tick (what the reference's node publishes every tick, src/target_manager_ros.cpp:78-87), written THROUGH the caches
@@ -134,10 +135,13 @@ __device__ __forceinline__ bool live_wait_tick(const long long* mirror, long lon
 // The relay wavefront: host doorbell -> device mirror, worker progress -> host.  Leaves when a stop was requested (by the
 // host, or by itself after `limit` polls without news from the host) and every worker has served the posted ticks.
 __device__ __forceinline__ void live_relay(const long long* posted, long long* mirror, const int* progress, int* done, long waves,
-                                           unsigned limit, int lane, int flags) {
+                                           unsigned limit, unsigned long long idle_ticks, int lane, int flags) {
   long long last = 0;
   int last_done = 0;
   unsigned idle = 0;   // consecutive rounds in which nothing happened: no news from the host, no progress of the workers
+  // ... and since when, on the device's constant-rate clock: the idle limit is a time (idle_ticks of wall_clock64; a round takes
+  // 1.5 - 5 us depending on the grid, so a count of rounds was 20 % short of the seconds asked for); the count remains the fallback
+  unsigned long long t_active = wall_clock64();
   // "running": the host set the word to -1 before the launch.  This is the LAST workgroup of the grid and workgroups are dispatched
   // in order, so the word also says that every worker has been given its wave slot (Batch::live_start waits for it).
   if (lane == 0) __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -173,22 +177,23 @@ __device__ __forceinline__ void live_relay(const long long* posted, long long* m
       last_done = mn;
     }
     const bool caught_up = (long long)mn >= (last & kLiveCount);
+    const bool idle_over = idle_ticks ? (idle > 0 && wall_clock64() - t_active >= idle_ticks) : idle >= limit;
     if (last < 0) v = last;                                    // stopping: the host's word no longer matters
-    else if (caught_up && idle >= limit) v = last | kLiveStop;  // everything served and a silent host: stop at what was posted
+    else if (caught_up && idle_over) v = last | kLiveStop;      // everything served and a silent host: stop at what was posted
     if (v != last) {
       const long groups = (waves + kLiveGroup - 1) / kLiveGroup;
       for (long g = lane; g < groups; g += 64)
         __hip_atomic_store(&mirror[g * kLiveMirrorStride], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       last = v;
-      idle = 0;
+      idle = 0; t_active = wall_clock64();
     } else if (progressed) {
-      idle = 0;   // the workers are busy with ticks already posted: that is not an idle host
+      idle = 0; t_active = wall_clock64();   // the workers are busy with ticks already posted: that is not an idle host
     } else {
       ++idle;
     }
     if (last < 0) {
       if ((long long)mn >= (last & kLiveCount)) break;   // every worker has served the posted ticks and is leaving
-      if (idle >= limit) break;                          // (a worker that never ran: nothing more to wait for)
+      if (idle_ticks ? (idle > 0 && wall_clock64() - t_active >= idle_ticks) : idle >= limit) break;   // (a worker that never ran: nothing more to wait for)
     }
     // The workers' progress stores and this wavefront's scan meet in the same lines: scanned back to back, a busy session's
     // ticks get slower (10^5 UA fp32: 1.2 -> 2.0 us per tick).  While the workers are more than a tick behind what is posted

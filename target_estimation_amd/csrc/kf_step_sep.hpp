@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR, LIVE>
   if constexpr (LIVE) {   // the workgroup behind the last worker is the relay between the host's words and the device's
     const long workers = (a.n + TPW - 1) / TPW;
     if (wg == workers) {
-      live_relay(a.live_posted, a.live_mirror, a.live_progress, a.live_done, workers, a.live_spin_limit, lane, a.live_flags);
+      live_relay(a.live_posted, a.live_mirror, a.live_progress, a.live_done, workers, a.live_spin_limit, a.live_idle_ticks, lane, a.live_flags);
       return;
     }
   }

@@ -444,6 +444,9 @@ int target_batch_live_wait(target_batch_c* b, long tick, double timeout_s) {
 long target_batch_live_stop(target_batch_c* b) {
   return guarded_value<long>("target_batch_live_stop", -1L, [&] { BatchLock lk(B(b)); return B(b)->live_stop(); });
 }
+int target_batch_live_running(target_batch_c* b) {
+  return guarded_value<int>("target_batch_live_running", -1, [&] { return B(b)->live_running() ? 1 : 0; });   // reads a host-mapped word: no lock
+}
 long target_batch_live_capacity(target_batch_c* b) {
   return guarded_value<long>("target_batch_live_capacity", -1L, [&] { return B(b)->live_capacity_targets(B(b)->live_pose_output_set()); });
 }

@@ -165,6 +165,10 @@ class Batch:
 
     live_capacity = property(lambda s: s._lib.target_batch_live_capacity(s._h))
 
+    def live_running(self):
+        """True while the session's resident kernel is there (it leaves after live_stop, or by itself after the idle limit)."""
+        return self._lib.target_batch_live_running(self._h) == 1
+
     def get_est(self, pose=True, twist=True, acc=True, t1=None):
         """Derived outputs of every slot as CUDA double tensors ([size,7], [size,6], [size,6])."""
         import torch
