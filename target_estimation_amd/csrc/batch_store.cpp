@@ -691,7 +691,11 @@ void Batch::live_start(double dt, const void* meas_ring, long tick_stride, long 
     if (q != hipErrorNotReady && q != hipSuccess) TE_HIP_CHECK(q);
     if (std::chrono::steady_clock::now() < t_end) continue;
     __atomic_store_n(live_.h_posted, kLiveStop, __ATOMIC_RELEASE);
-    live_.zombie = true;   // flush() waits for it before anything touches the records
+    // (workers that did get a wave slot look at the host's word themselves every millisecond or two: they leave, the rest of the
+    // grid gets their slots, sees the stop and leaves too; the records are back as they were)
+    const auto t_gone = std::chrono::steady_clock::now() + std::chrono::duration<double>(1.0);
+    while (hipStreamQuery(live_.stream) == hipErrorNotReady && std::chrono::steady_clock::now() < t_gone) __builtin_ia32_pause();
+    live_.zombie = hipStreamQuery(live_.stream) == hipErrorNotReady;   // still queued behind somebody else's kernel: flush() waits for it before anything touches the records
     throw std::runtime_error("target_estimation_amd: live mode: the resident kernel did not start within " + std::to_string(kLiveStartTimeoutS) +
                              " s (its stream shares a hardware queue with another endless kernel -- more live batches than GPU_MAX_HW_QUEUES, or a "
                              "high-priority stream of the caller -- or the device is busy)");

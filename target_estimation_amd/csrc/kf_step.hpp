@@ -119,7 +119,10 @@ __device__ __forceinline__ long long wave_uniform_ll(long long v) {
 // the backstop limit ran out).  `seen` caches the last value read, so a wavefront that is behind catches up without
 // polling.  ONE lane reads the mirror word (a device-scope atomic load on the vector path: the scalar cache may hold a
 // stale copy; 64 lanes loading one address past the caches would be 64 requests).
-__device__ __forceinline__ bool live_wait_tick(const long long* mirror, long long need, unsigned limit, long long& seen, int lane) {
+// Every 4096th poll (a millisecond or two of waiting) the wavefront also looks at the host's own word, over PCIe: a stop there with
+// nothing left to serve ends it even when the relay is not there to pass it on -- a grid that never became fully resident, which
+// Batch::live_start gives up on (the relay is its LAST workgroup).  A busy session never waits that long between ticks.
+__device__ __forceinline__ bool live_wait_tick(const long long* mirror, const long long* host_posted, long long need, unsigned limit, long long& seen, int lane) {
   if ((seen & kLiveCount) >= need) return true;
   for (unsigned spins = 0;; ++spins) {
     long long v = 0;
@@ -128,6 +131,12 @@ __device__ __forceinline__ bool live_wait_tick(const long long* mirror, long lon
     if ((seen & kLiveCount) >= need) return true;
     if (seen < 0) return false;        // stop, and every posted tick is done
     if (spins >= limit) return false;  // backstop (the relay stops the session long before)
+    if ((spins & 4095u) == 4095u) {
+      long long h = 0;
+      if (lane == 0) h = __hip_atomic_load(host_posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      h = wave_uniform_ll(h);
+      if (h < 0 && (h & kLiveCount) < need) return false;
+    }
     __builtin_amdgcn_s_sleep(4);
   }
 }

@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR, LIVE>
   long slot_tick = tick;
   if constexpr (LIVE) {
     // (the worker's own limit is a backstop far behind the relay's: a relay round is a PCIe read + a scan, a worker poll an L2 hit)
-    if (!live_wait_tick(a.live_mirror + (wave_id / kLiveGroup) * kLiveMirrorStride, (long long)tick + 1, a.live_spin_limit < 0x07ffffffu ? 32u * a.live_spin_limit + 10000000u : 0xffffffffu, live_seen, lane)) break;
+    if (!live_wait_tick(a.live_mirror + (wave_id / kLiveGroup) * kLiveMirrorStride, a.live_posted, (long long)tick + 1, a.live_spin_limit < 0x07ffffffu ? 32u * a.live_spin_limit + 10000000u : 0xffffffffu, live_seen, lane)) break;
     slot_tick = (a.live_first + tick) % a.live_ring;
   }
   const T* meas_t = a.meas ? a.meas + slot_tick * a.tick_stride : nullptr;

@@ -465,3 +465,44 @@ def test_sessions_with_one_hardware_queue_per_priority():
     env = dict(os.environ, GPU_MAX_HW_QUEUES="1", PYTHONPATH=os.pathsep.join([os.path.dirname(__file__), os.path.dirname(os.path.dirname(__file__))]))
     p = subprocess.run([sys.executable, "-c", "import test_gpu_live as t; t._one_hardware_queue_case()"], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "one hardware queue ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
+def test_a_second_session_that_does_not_fit_next_to_the_first_is_refused_cleanly(models):
+    """Two managers, each within ITS capacity, together more than the device holds: the second session's grid is only partly
+    resident, its last workgroup (the relay) never starts.  live_start must say so after its start timeout, get the workers
+    that did start out of the way (the stop word goes into their mirror words from the host), leave the second manager usable
+    at once -- and the first session must go on serving ticks."""
+    import time
+    name, dtype, dt = "uniform_acceleration", "f32", 0.004
+    probe = te.TargetManager(model_path(name), dtype=dtype)
+    p1 = np.zeros((64, 7)); p1[:, 6] = 1
+    probe.init_batch(np.arange(64, dtype=np.uint32), dt, 0.0, p1)
+    cap = probe.batches()[0].live_capacity
+    probe.close()
+    na, nb = int(cap * 0.95) // 64 * 64, int(cap * 0.6) // 64 * 64
+    mgr_a, a, st_a, ids_a, p0_a, live_a = _setup(models, name, dtype, na, 8, dt, 3)
+    mgr_b, b, st_b, ids_b, p0_b, live_b = _setup(models, name, dtype, nb, 8, dt, 4)
+    a.live_start(dt, st_a["meas"], max_ticks=8, idle_limit_s=20.0)
+    a.live_post(2)
+    assert a.live_wait(2, 5.0)
+    t0 = time.perf_counter()
+    with pytest.raises(RuntimeError, match="did not start within"):
+        b.live_start(dt, st_b["meas"], max_ticks=8, idle_limit_s=20.0)
+    assert time.perf_counter() - t0 < 6.0
+    t0 = time.perf_counter()
+    ok, pose = mgr_b.getTargetPose(int(ids_b[5]))               # the refused manager: usable at once, records untouched
+    assert ok and np.allclose(pose[:3], p0_b[5, :3])
+    b.step(dt, st_b["meas"][0])
+    mgr_b.synchronize()
+    assert time.perf_counter() - t0 < 2.0
+    # (calls that FREE device memory -- get_state_batch's scratch buffers, a batch that grows -- wait for every kernel of the
+    # process, a resident one included: hipFree synchronises the device.  Not used next to somebody else's session.)
+    a.live_post(6)                                              # the first session never noticed
+    assert a.live_wait(8, 5.0) and a.live_stop() == 8
+    ref = te.TargetManager(model_path(name), dtype=dtype)
+    ref.init_batch(ids_b, dt, 0.0, p0_b)
+    ref.batches()[0].step(dt, st_b["meas"][0])
+    want, got = ref.get_state_batch(ids_b[::997]), mgr_b.get_state_batch(ids_b[::997])
+    np.testing.assert_array_equal(got[0], want[0])
+    np.testing.assert_array_equal(got[1], want[1])
+    ref.close(); mgr_a.close(); mgr_b.close()
