@@ -180,6 +180,7 @@ Batch::~Batch() {
   (void)hipFree(d_dtper_); (void)hipFree(d_lastmeas_);
   if (h_pin_) (void)hipHostFree(h_pin_);
   if (h_cache_) (void)hipHostFree(h_cache_);
+  (void)hipFree(d_state_scratch_);
   if (h_done_) (void)hipHostFree(h_done_);
   if (live_.h_posted) (void)hipHostFree(live_.h_posted);
   (void)hipFree(live_.d_block);
@@ -1126,16 +1127,33 @@ void Batch::get_state(const int* slots, long n, double* x, double* P) {
   const int N = ops_->L.n;
   stage_reserve(n);
   if (slots) upload_slots(slots, n);
-  double* dx = nullptr;
-  double* dP = nullptr;
-  if (x) TE_HIP_CHECK(hipMalloc((void**)&dx, sizeof(double) * N * n));
-  if (P) TE_HIP_CHECK(hipMalloc((void**)&dP, sizeof(double) * N * N * n));
+  // scratch: up to kStateScratchKeep bytes are kept between calls (a caller reading one target's covariance at a time -- the
+  // reference test's getEstimator()->getP() -- pays no allocation, and no hipFree: that synchronises the whole device, a
+  // resident kernel of another batch included); larger requests are freed again
+  const size_t bx = x ? sizeof(double) * (size_t)N * n : 0, bP = P ? sizeof(double) * (size_t)N * N * n : 0;
+  char* big = nullptr;
+  char* buf = nullptr;
+  if (bx + bP <= kStateScratchKeep) {
+    if (bx + bP > state_scratch_bytes_) {
+      TE_HIP_CHECK(hipStreamSynchronize(stream_));
+      (void)hipFree(d_state_scratch_); d_state_scratch_ = nullptr; state_scratch_bytes_ = 0;
+      const size_t want = std::max<size_t>(bx + bP, std::min<size_t>(2 * state_scratch_bytes_ + 4096, kStateScratchKeep));
+      TE_HIP_CHECK(hipMalloc((void**)&d_state_scratch_, want));
+      state_scratch_bytes_ = want;
+    }
+    buf = d_state_scratch_;
+  } else {
+    TE_HIP_CHECK(hipMalloc((void**)&big, bx + bP));
+    buf = big;
+  }
+  double* dx = x ? reinterpret_cast<double*>(buf) : nullptr;
+  double* dP = P ? reinterpret_cast<double*>(buf + bx) : nullptr;
   ops_->get_state(d_rec_, slots ? d_idx_ : nullptr, n, dx, dP, stream_);
   TE_HIP_CHECK(hipGetLastError());
-  if (x) TE_HIP_CHECK(hipMemcpyAsync(x, dx, sizeof(double) * N * n, hipMemcpyDeviceToHost, stream_));
-  if (P) TE_HIP_CHECK(hipMemcpyAsync(P, dP, sizeof(double) * N * N * n, hipMemcpyDeviceToHost, stream_));
+  if (x) TE_HIP_CHECK(hipMemcpyAsync(x, dx, bx, hipMemcpyDeviceToHost, stream_));
+  if (P) TE_HIP_CHECK(hipMemcpyAsync(P, dP, bP, hipMemcpyDeviceToHost, stream_));
   TE_HIP_CHECK(hipStreamSynchronize(stream_));
-  (void)hipFree(dx); (void)hipFree(dP);
+  if (big) (void)hipFree(big);
 }
 
 void Batch::set_state(const int* slots, long n, const double* x, const double* P, const double* unwrap) {

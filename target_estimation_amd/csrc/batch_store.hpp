@@ -302,6 +302,9 @@ class Batch {
   static constexpr int kBigDirect = 64;
   long epoch_getters_ = 0;                   // one-target getters since the last change
   bool big_sweeps_ = false;                  // the last epoch of this (large) batch was a sweep
+  static constexpr size_t kStateScratchKeep = 16u << 20;   // get_state's device scratch kept between calls up to this size
+  char* d_state_scratch_ = nullptr;
+  size_t state_scratch_bytes_ = 0;
   static constexpr int kCounterDirect = 4;   // single reads of a measurement counter before all of them are copied to the host
   std::vector<int> h_nm_;
   bool nm_valid_ = false;
