@@ -84,6 +84,15 @@ def test_null_handles_are_errors_not_crashes(capfd):
     assert lib.target_batch_step(None, 0.004, None, 0, None) != 0
     assert lib.target_manager_step_sequence_all(None, 1, 0.004, None, 0, 0, None, 0.0, 0) != 0
     assert lib.target_manager_size(None) < 0
+    # the resident mode and the stream generator: NULL handles / descriptions are errors too
+    assert lib.target_batch_live_start(None, 0.004, None, 0, 0, None, 0, 0, 0, 1, 1.0) != 0
+    assert lib.target_batch_live_post(None, 1) != 0 and lib.target_batch_live_post_each(None, 1) != 0
+    assert lib.target_batch_live_done(None) == -1 and lib.target_batch_live_stop(None) == -1
+    assert lib.target_batch_live_running(None) == -1 and lib.target_batch_live_capacity(None) == -1
+    assert lib.target_batch_live_wait(None, 1, 0.0) != 0
+    assert lib.target_manager_live_start_all(None, 0.004, None, 0, 0, 1, 1.0, 0, None, 0.0) != 0
+    assert lib.target_manager_live_post_all(None, 1, 0) != 0 and lib.target_manager_live_stop_all(None) == -1
+    assert lib.target_stream_fill_dev(None, 1, 0, 1, 0, None, 0, 0, None, 0, None) != 0
     assert b"NULL" in lib.target_manager_last_error()
     assert "NULL manager handle" in capfd.readouterr().err
 
