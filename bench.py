@@ -127,11 +127,13 @@ MIXED = {
 }
 HEADLINE = "cfg4_1gpu"
 
-DEFAULT_EXTRA = ("cfg2,cfg2_live,cfg2_stream,cfg3,cfg3_live,cfg3_stream,cfg4,cfg4_live,cfg4_64,cfg5,cfg5_live,cfg4_1gpu32,cfg5_1gpu,cfg5_1gpu64,"
+DEFAULT_EXTRA = ("cfg2,cfg2_live,cfg2_stream,cfg3,cfg3_live,cfg3_stream,cfg4,cfg4_live,cfg4_64,cfg4_64_live,cfg5,cfg5_live,cfg4_1gpu32,cfg5_1gpu,cfg5_1gpu64,"
                  "uv1m,uv1m32,ua1m64,ua1m,av1m64,av1m,ar1m64,ar1m,"
                  "uv10m,ua10m,av4m64,ar4m64,av8m,ar8m,cfg4_4m,"
                  "ar1m_a90,av1m_a90,ar1m64_1kcls,ar1m64_1kcls_rand,ar100k64_1kcls,uv1m_1kcls,uv1m_full,uv1m_packed,ar1m_full,ar1m_packed,av1m_packed,ar1m64_full,av1m64_full,ar1m64_packed,av1m64_packed")
-DEFAULT_EXTRA_MULTI = "uv1m,ua1m64,av1m64,ar1m64,cfg4_64,cfg5,uv1m_strong,ar1m64_strong"
+# N > 1: BASELINE configs[3] / configs[4] as they are stated -- 10^6 targets OVER the N GPUs (strong scaling; at N = 8 these are the
+# 62 500 + 62 500 shares) -- come first, so that a deadline cuts the per-model rows, not them
+DEFAULT_EXTRA_MULTI = "cfg4_1gpu_strong,cfg4_1gpu32_strong,cfg5_1gpu_strong,uv1m_strong,ar1m64_strong,uv1m,ua1m64,av1m64,ar1m64"
 # On request only (--extra cfg4_1gpu_replay,cfg4_4m_replay): the mixed populations with the batches' chains free-running inside graph
 # blocks.  Not in the default line: they launch the headline's kernels at the headline's grid CONCURRENTLY, which would mix overlapped
 # durations into the per-kernel averages of the rocprofv3 summary that goes with the default command (profiles/r02_mixed_replay_trace.txt).
@@ -465,7 +467,7 @@ def run_live_mixed(te, torch, name, desc, parts, dtype, mgr, batches, meas, dt, 
     return res
 
 
-def run_mixed(te, torch, name, steps, warmup, dist=None, rank=0, world=1, stream_ticks=64, launch_mode="auto", reps=3):
+def run_mixed(te, torch, name, steps, warmup, dist=None, rank=0, world=1, stream_ticks=64, launch_mode="auto", reps=3, split=1):
     """Several motion models (batches) in one manager, one step launch per batch per tick; the sphere query of
     configs[4] runs inside the step kernels.  Launch-bound populations: the batches are concurrent branches of ONE
     recorded hipGraph (target_manager_step_sequence_all).  Large populations: plain launches in tick order on the
@@ -474,6 +476,8 @@ def run_mixed(te, torch, name, steps, warmup, dist=None, rank=0, world=1, stream
     import numpy as np
     from target_estimation_amd.streams import make_stream
     desc, parts, dtype, seed, intersect = MIXED[name]
+    if split > 1:   # strong scaling: this rank's share of every model (N_model / N per GPU per model)
+        parts = [(m, n // split) for m, n in parts]
     n_all = sum(n for _, n in parts)
     if launch_mode == "auto":
         launch_mode = "graph" if n_all <= SMALL else "sequence"
@@ -760,6 +764,36 @@ def configs0_report(te, torch, steps=(1000, 10000)):
     return out
 
 
+def start_watchdog(what, rank, deadline_s, grace_s=5.0):
+    """A daemon thread that ends THIS process (status 3, with a diagnostic) unless the returned event is set within
+    deadline_s + grace_s: whatever `what` is -- a collective entry a peer never reaches, a send that never completes -- a
+    rank that is alone in it must neither hang the job nor be re-executed.  Returns (event, absolute deadline)."""
+    done = threading.Event()
+    t_end = time.monotonic() + deadline_s
+
+    def watchdog():
+        if not done.wait(deadline_s + grace_s):
+            print("bench.py rank %d: %s still not finished %.0f s after its start (communicator set-up or a peer's "
+                  "send/recv never completed); giving up" % (rank, what, deadline_s + grace_s), file=sys.stderr)
+            sys.stderr.flush()
+            os._exit(3)
+    threading.Thread(target=watchdog, daemon=True).start()
+    return done, t_end
+
+
+def gather_rehearsal(dist, rank, world, deadline_s):
+    """--dry-run with N > 1: the gather's collective entry (the communicator set-up of gather_report is one) under the same
+    watchdog, with a barrier standing for it.  TE_BENCH_TEST_LATE_RANK=R:SECONDS makes rank R arrive that late (tests)."""
+    late = os.environ.get("TE_BENCH_TEST_LATE_RANK", "")
+    if late:
+        r, sec = late.split(":")
+        if int(r) == rank:
+            time.sleep(float(sec))   # still busy with something else: it has not entered the gather yet
+    done, _ = start_watchdog("pose gather", rank, deadline_s, grace_s=1.0)
+    dist.barrier()
+    done.set()
+
+
 def gather_report(te, torch, dist, rank, world, workload="ar1m64", ticks=16, deadline_s=60.0):
     """The library's RCCL pose gather (target_manager_gather_pose_*: direct sends to rank 0 on a second stream behind an
     event).  Exposed = begin + wait with nothing else running; overlapped = begin, then `ticks` ticks, then wait: what
@@ -770,17 +804,7 @@ def gather_report(te, torch, dist, rank, world, workload="ar1m64", ticks=16, dea
     # Bounded: a peer that never arrives (communicator set-up is collective) must not hang the run.  A watchdog thread ends
     # the process with a diagnostic after deadline_s; the waits themselves poll hipEventQuery against the same deadline
     # (target_manager_gather_pose_wait_for).  Nothing is re-executed.
-    import threading
-    t_end = time.monotonic() + deadline_s
-    done = threading.Event()
-
-    def watchdog():
-        if not done.wait(deadline_s + 5.0):
-            print("bench.py rank %d: pose gather still not finished %.0f s after its start (communicator set-up or a peer's "
-                  "send/recv never completed); giving up" % (rank, deadline_s + 5.0), file=sys.stderr)
-            sys.stderr.flush()
-            os._exit(3)
-    threading.Thread(target=watchdog, daemon=True).start()
+    done, t_end = start_watchdog("pose gather", rank, deadline_s)
     g = PoseGather(mgr)
     g.deadline = t_end
     counts = g.counts()
@@ -1054,12 +1078,17 @@ def main():
         wall, _ = Clock(torch, dist, device=False).measure(lambda k: time.sleep(0.0005 * k), args.steps, args.reps)
         if dist is not None:
             dist.barrier()
-            dist.destroy_process_group()
+        line = {"metric": "KF predict+update cycles/sec over N targets", "value": None, "unit": "cycles/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": median(wall) * 1e3 / args.steps,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+                "data": "dry-run: no device work", "config": {"workload": "dry-run of the rank start-up and timing protocol"}}
         if rank == 0:
-            emit({"metric": "KF predict+update cycles/sec over N targets", "value": None, "unit": "cycles/s", "n_gpus": world,
-                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": median(wall) * 1e3 / args.steps,
-                  "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-                  "data": "dry-run: no device work", "config": {"workload": "dry-run of the rank start-up and timing protocol"}})
+            emit(line)   # first, as in a real run: nothing behind the line can cost it
+        if dist is not None:
+            if not args.no_gather:
+                gather_rehearsal(dist, rank, world, args.gather_deadline)
+            dist.barrier()
+            dist.destroy_process_group()
         return
 
     import target_estimation_amd as te
@@ -1138,16 +1167,19 @@ def main():
     # barriers on one rank only) must not leave the job hanging at the others' barrier.  After --post-deadline seconds every
     # rank says so and leaves (exit 0: the record stands; the side file says what is missing).
     extras = []
+    running = {"name": None}   # the extra (or "gather_pose") in progress: what a stall is blamed on
 
     def post_deadline():
-        print("bench.py: rank %d: extras / gather did not finish within %.0f s; leaving (the line was printed)" % (rank, args.post_deadline),
-              file=sys.stderr, flush=True)
+        # status 4, not 0: a hang or a stalled resident session in an extra is a failure of that extra, and the record must say
+        # which one (the line itself is out and stands)
+        print("bench.py: rank %d: extras / gather did not finish within %.0f s (running: %s); leaving with status 4 (the line was printed)" % (
+            rank, args.post_deadline, running["name"]), file=sys.stderr, flush=True)
         if rank == 0:
             try:
-                write_side(args, dict(side, line=out, extra=list(extras), extras_incomplete=True))
+                write_side(args, dict(side, line=out, extra=list(extras), extras_incomplete=True, stalled_in=running["name"]))
             except Exception:
                 pass
-        os._exit(0)
+        os._exit(4)
     post_timer = threading.Timer(args.post_deadline, post_deadline)
     post_timer.daemon = True
     post_timer.start()
@@ -1157,6 +1189,7 @@ def main():
     for name in extra_names:
         if name == args.workload:
             continue
+        running["name"] = name
         try:
             if name.endswith("_replay"):
                 # The same population with the batches' chains FREE-RUNNING inside recorded graph blocks (one branch per batch,
@@ -1179,6 +1212,13 @@ def main():
                 else:
                     r = run_workload(te, torch, wl, args.extra_steps, 64, 0, dist=dist, rank=rank, world=world, launch_mode="live", reps=5)
                 r["name"] = name
+            elif name.endswith("_strong") and name[:-len("_strong")] in MIXED:   # a mixed population split over the ranks, model by model
+                wl = name[:-len("_strong")]
+                small = sum(n for _, n in MIXED[wl][1]) // world <= SMALL
+                r = run_mixed(te, torch, wl, 512 if small else args.extra_steps, 64 if small else 8, dist, rank, world,
+                              launch_mode="auto" if args.launch_mode in ("fused", "live") else args.launch_mode, reps=3, split=world)
+                r["name"] = name
+                r["desc"] += " -- strong scaling: the population split over %d GPUs, every model evenly" % world
             elif name.endswith("_strong"):                  # strong scaling: the workload's targets split over the ranks
                 wl = name[:-len("_strong")]
                 per_rank = WORKLOADS[wl][3] // world
@@ -1205,6 +1245,7 @@ def main():
         maps_checkpoint(name)
     # RCCL needs one GPU per rank: a gloo rehearsal (several ranks on ONE GPU) cannot create the communicator
     if not args.no_gather and (world == 1 or dist.get_backend() == "nccl"):
+        running["name"] = "gather_pose"
         try:
             gr = gather_report(te, torch, dist, rank, world, deadline_s=args.gather_deadline)
             extras.append(gr)

@@ -56,6 +56,50 @@ def test_driver_style_launch_is_accepted():
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
 
 
+def test_world_size_8_dry_run_through_the_drivers_launcher():
+    """The driver's N = 8 command shape with gloo and no device work: eight ranks rendezvous, the counting all-reduce sees eight,
+    the barrier-bracketed repetitions run, ONE short line comes out of rank 0, and the gather rehearsal's collective completes."""
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29641", BENCH, "--gpus", "8", "--steps", "6", "--warmup", "2", "--dry-run"]
+    p = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["steps"] == 6 and line["scaling"] == "weak" and line["value"] is None
+
+
+def test_a_late_rank_costs_status_3_and_a_diagnostic_not_a_hang():
+    """One of two ranks reaches the gather's collective entry later than the deadline allows: the punctual rank's watchdog ends
+    it with status 3 and says why; the job ends (nobody waits for ever); the line was printed before and stands."""
+    import time
+    t0 = time.time()
+    p, line = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--dry-run", "--gather-deadline", "2"],
+                   env={"TE_BENCH_TEST_LATE_RANK": "1:30"}, timeout=120)
+    took = time.time() - t0
+    assert p.returncode != 0
+    assert "bench.py rank 0: pose gather still not finished" in p.stderr          # the punctual rank says why it leaves
+    assert "bench.py rank 1: pose gather" not in p.stderr                         # the late one never got as far as the gather
+    assert "exitcode: 3" in p.stderr                                              # ... and leaves with status 3 (the launcher's report)
+    assert line is not None and line["n_gpus"] == 2          # the line went out first
+    assert took < 60, took                                   # the late rank (30 s) was not waited for
+
+
+def test_strong_scaling_rows_come_first_for_n_gt_1():
+    sys.path.insert(0, ROOT)
+    import bench
+    names = bench.DEFAULT_EXTRA_MULTI.split(",")
+    assert names[:3] == ["cfg4_1gpu_strong", "cfg4_1gpu32_strong", "cfg5_1gpu_strong"]
+    first_weak = min(i for i, n in enumerate(names) if not n.endswith("_strong"))
+    assert all(n.endswith("_strong") for n in names[:first_weak]) and first_weak >= 5
+    for n in names:
+        base = n[:-len("_strong")] if n.endswith("_strong") else n
+        assert base in bench.WORKLOADS or base in bench.MIXED
+
+
 def _fake_result():
     """A result record of the shape run_mixed() returns, with the longest strings bench.py can produce."""
     sys.path.insert(0, ROOT)
