@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""High-precision known answers for the four motion models: steps 1-4 of one target each, evaluated in 50-digit arithmetic
+(mpmath) from formulas typed from the REFERENCE sources -- not from oracle/ -- so that "the oracle, the NumPy twin and the
+kernels share a misreading" and "they differ by rounding" can be told apart.
+
+    python tests/golden/make_highprec_kat.py        ->  tests/golden/highprec_kat.npz
+
+What is evaluated, with the reference lines it follows:
+  predict   x- = A x (linear) or f(x) (EKF);  P- = A P A^T + Q                      src/kalman.cpp:84-88, :129-133
+  estimate  K = P- C^T (C P- C^T + R)^-1;  x+ = x- + K (y - C x-);  P+ = (I - K C) P-   src/kalman.cpp:90-95, :135-140
+  A(dt)     I + dt on the n/2 (n/3) diagonal + dt^2/2 on the 2n/3 diagonal           src/types/uniform_velocity.cpp:90-96,
+                                                                                     uniform_acceleration.cpp:91-99, angular_rates.cpp:108-115
+  EKF       A = [I 0 dt I 0; 0 Jrpy 0 Jomega; 0 0 I 0; 0 0 0 I] at the target's own previous posterior,
+            f = [p + dt v; rpy + dt Einv(rpy) omega; v; omega], h = first six states   src/types/angular_velocities.cpp:116-150,
+                                                                                     include/target_estimation/geometry.hpp:359-426
+  measurement (angular models): quaternion normalised, quatToRpy, unwrap against the previous unwrapped angles
+                                                                                     angular_rates.cpp:81-88, geometry.hpp:31-76, :154-176
+  initial state: position and rpy of p0, zero rates; P = P0                           src/types/*.cpp constructors, geometry.hpp:619-628
+The reference never initialises the unwrap memory (meas_rpy_internal_); zero is used here, as everywhere in this
+repository.  Inputs are doubles (the YAML matrices as parsed to double, dt = 1/250, the poses below); every operation after that
+is carried out in 50 digits and the results are rounded once, to double, at the end.
+"""
+import os
+
+import numpy as np
+import yaml
+from mpmath import mp, mpf, matrix, sin, cos, atan2, asin, sqrt, floor, pi as mp_pi_f
+
+mp.dps = 50
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+M_PI = mpf(float(np.pi))    # the reference's M_PI is the double nearest to pi
+
+
+def c_fmod(x, y):           # C fmod: x - trunc(x / y) * y, sign of x
+    q = x / y
+    t = floor(q) if q >= 0 else -floor(-q)
+    return x - t * y
+
+
+def constrain_angle(x):     # geometry.hpp:31-36
+    x = c_fmod(x + M_PI, 2 * M_PI)
+    if x < 0:
+        x += 2 * M_PI
+    return x - M_PI
+
+
+def angle_conv(a):          # geometry.hpp:43-45
+    return c_fmod(constrain_angle(a), 2 * M_PI)
+
+
+def angle_diff(a, b):       # geometry.hpp:53-58
+    d = c_fmod(b - a + M_PI, 2 * M_PI)
+    if d < 0:
+        d += 2 * M_PI
+    return d - M_PI
+
+
+def unwrap(prev, new):      # geometry.hpp:70-76
+    return prev - angle_diff(new, angle_conv(prev))
+
+
+def quat_to_rpy(q):         # geometry.hpp:154-176, q = [x y z w], normalised by the caller
+    x, y, z, w = q
+    sp = -2 * (x * z - w * y)
+    if sp > mpf("0.9999"):
+        return [mpf(0), M_PI / 2, 2 * atan2(z, w)]
+    if sp < mpf("-0.9999"):
+        return [mpf(0), -M_PI / 2, 2 * atan2(z, w)]
+    return [atan2(2 * (y * z + w * x), w * w - x * x - y * y + z * z), asin(sp), atan2(2 * (x * y + w * z), w * w + x * x - y * y - z * z)]
+
+
+def normalised(q):          # Eigen::Quaterniond::normalize
+    n = sqrt(sum(c * c for c in q))
+    return [c / n for c in q]
+
+
+def pose7_to_meas6(pose7, memory):
+    """xyz + unwrapped rpy of a measured pose (angular_rates.cpp:81-88); returns (y6, new memory)"""
+    rpy = quat_to_rpy(normalised([mpf(v) for v in pose7[3:7]]))
+    un = [unwrap(memory[i], rpy[i]) for i in range(3)]
+    return [mpf(v) for v in pose7[0:3]] + un, un
+
+
+def transition_linear(n, nb, dt):
+    A = mp.eye(n)
+    k = n // nb
+    for r in range(n - k):
+        A[r, r + k] = dt
+    if nb == 3:
+        for r in range(n - 2 * k):
+            A[r, r + 2 * k] = mpf("0.5") * dt * dt
+    return A
+
+
+def ekf_transition(x, dt):  # angular_velocities.cpp:116-124 with geometry.hpp:394-426
+    r, p = x[3], x[4]
+    wy, wz = x[10], x[11]
+    cr, sr, cp, sp = cos(r), sin(r), cos(p), sin(p)
+    A = mp.zeros(12)
+    for i in range(3):
+        A[i, i] = 1
+        A[i, 6 + i] = dt
+        A[6 + i, 6 + i] = 1
+        A[9 + i, 9 + i] = 1
+    J = [[(dt * (wy * cr * sp - wz * sp * sr)) / cp + 1, (dt * (wz * cr + wy * sr)) / (cp * cp), 0],
+         [-dt * (wz * cr + wy * sr), 1, 0],
+         [(dt * (wy * cr - wz * sr)) / cp, (dt * sp * (wz * cr + wy * sr)) / (cp * cp), 1]]
+    W = [[dt, (dt * sp * sr) / cp, (dt * cr * sp) / cp],
+         [0, dt * cr, -dt * sr],
+         [0, (dt * sr) / cp, (dt * cr) / cp]]
+    for i in range(3):
+        for j in range(3):
+            A[3 + i, 3 + j] = J[i][j]
+            A[3 + i, 9 + j] = W[i][j]
+    return A
+
+
+def ekf_f(x, dt):           # angular_velocities.cpp:126-140 with geometry.hpp:359-374
+    r, p = x[3], x[4]
+    cr, sr, cp, sp = cos(r), sin(r), cos(p), sin(p)
+    E = [[1, (sp * sr) / cp, (cr * sp) / cp], [0, cr, -sr], [0, sr / cp, cr / cp]]
+    out = [mpf(0)] * 12
+    for i in range(3):
+        out[i] = x[i] + dt * x[6 + i]
+        out[3 + i] = x[3 + i] + dt * sum(E[i][j] * x[9 + j] for j in range(3))
+        out[6 + i] = x[6 + i]
+        out[9 + i] = x[9 + i]
+    return out
+
+
+def run(model, Q, R, P0, p0, dt, stream):
+    n, m = Q.rows, R.rows
+    angular = model in ("angular_rates", "angular_velocities")
+    x = [mpf(0)] * n
+    for i in range(3):
+        x[i] = mpf(p0[i])
+    if angular:
+        rpy0 = quat_to_rpy(normalised([mpf(v) for v in p0[3:7]]))   # pose7dToPose6d, geometry.hpp:619-628
+        for i in range(3):
+            x[3 + i] = rpy0[i]
+    P = P0.copy()
+    memory = [mpf(0)] * 3
+    C = mp.zeros(m, n)
+    for i in range(m):
+        C[i, i] = 1
+    I = mp.eye(n)
+    xs, Ps = [], []
+    for meas in stream:
+        if model == "angular_velocities":
+            A = ekf_transition(x, dt)
+            xp = ekf_f(x, dt)
+        else:
+            A = transition_linear(n, 2 if model == "uniform_velocity" else 3, dt)
+            xp = list(A * matrix(x))
+        P = A * P * A.T + Q
+        if meas is not None:
+            if angular:
+                y, memory = pose7_to_meas6(meas, memory)
+            else:
+                y = [mpf(v) for v in meas[0:3]]
+            S = C * P * C.T + R
+            K = P * C.T * (S ** -1)
+            innov = matrix([y[i] - xp[i] for i in range(m)])
+            xp = list(matrix(xp) + K * innov)
+            P = (I - K * C) * P
+        x = xp
+        xs.append([float(v) for v in x])
+        Ps.append([[float(P[i, j]) for j in range(n)] for i in range(n)])
+    return np.array(xs), np.array(Ps)
+
+
+def rpy_quat(r, p, y):      # only to WRITE test inputs (plain double arithmetic; the result is the input)
+    cr, sr, cp, sp, cy, sy = np.cos(r / 2), np.sin(r / 2), np.cos(p / 2), np.sin(p / 2), np.cos(y / 2), np.sin(y / 2)
+    return [sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy]
+
+
+def main():
+    dt = 1.0 / 250.0
+    # one target per model: initial pose, then four ticks: measured, measured, predict only, measured.  The yaw of the
+    # measurements crosses +pi between ticks 1 and 2 (the unwrap must carry it), the quaternions are not unit length
+    p0 = np.array([0.3, -0.2, 0.1] + [2.0 * c for c in rpy_quat(0.1, -0.2, 3.0)])
+    stream = [np.array([0.3105, -0.1958, 0.1012] + [1.5 * c for c in rpy_quat(0.11, -0.19, 3.1)]),
+              np.array([0.3192, -0.1911, 0.1043] + [0.7 * c for c in rpy_quat(0.12, -0.18, -3.08)]),
+              None,
+              np.array([0.3391, -0.1832, 0.1077] + [1.1 * c for c in rpy_quat(0.15, -0.16, -2.9)])]
+    out = {"dt": np.array(dt), "p0": p0, "has": np.array([s is not None for s in stream]),
+           "meas": np.array([s if s is not None else np.zeros(7) for s in stream])}
+    for model in ("uniform_velocity", "uniform_acceleration", "angular_rates", "angular_velocities"):
+        y = yaml.safe_load(open(os.path.join(ROOT, "models", "model_%s_params.yaml" % model)))
+        n = {"uniform_velocity": 6, "uniform_acceleration": 9, "angular_rates": 18, "angular_velocities": 12}[model]
+        m = 3 if n < 12 else 6
+        Q = matrix(n, n); R = matrix(m, m); P0 = matrix(n, n)
+        for i in range(n):
+            for j in range(n):
+                Q[i, j] = mpf(float(y["Q"][i * n + j]))
+                P0[i, j] = mpf(float(y["P"][i * n + j]))
+        for i in range(m):
+            for j in range(m):
+                R[i, j] = mpf(float(y["R"][i * m + j]))
+        xs, Ps = run(model, Q, R, P0, p0, mpf(dt), stream)
+        out["x_" + model] = xs
+        out["P_" + model] = Ps
+        print(model, "x after tick 4:", xs[-1][:6])
+    np.savez(os.path.join(HERE, "highprec_kat.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()
