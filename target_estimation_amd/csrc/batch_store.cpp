@@ -7,13 +7,58 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "hip_check.hpp"
 #include "intersect_gate.hpp"
 
 namespace te {
+
+namespace {
+std::mutex g_live_mu;
+std::vector<void*> g_deferred_frees;
+int g_live_sessions = 0;
+double g_live_share = 0.0;
+}  // namespace
+
+void device_free(void* p) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lg(g_live_mu);
+    if (g_live_sessions > 0) { g_deferred_frees.push_back(p); return; }
+  }
+  (void)hipFree(p);
+}
+
+bool live_session_begin(double share) {
+  std::lock_guard<std::mutex> lg(g_live_mu);
+  const char* e = std::getenv("TE_LIVE_IGNORE_OTHERS");   // tests: the start-word path of a grid that does not become resident
+  if (!(e && e[0] == '1') && g_live_sessions > 0 && g_live_share + share > 1.0) return false;
+  ++g_live_sessions;
+  g_live_share += share;
+  return true;
+}
+
+void live_session_ended(double share) {
+  std::vector<void*> drain;
+  {
+    std::lock_guard<std::mutex> lg(g_live_mu);
+    g_live_share -= share;
+    if (--g_live_sessions > 0) return;
+    g_live_sessions = 0; g_live_share = 0.0;
+    drain.swap(g_deferred_frees);
+  }
+  for (void* p : drain) (void)hipFree(p);
+}
+
+double live_sessions_share() {
+  std::lock_guard<std::mutex> lg(g_live_mu);
+  return g_live_share;
+}
+
 
 const Ops* get_ops(int type, int dtype, int g) {
   switch (type) {
@@ -57,7 +102,7 @@ int Batch::add_class(const double* Q, const double* R) {
       TE_HIP_CHECK(hipStreamSynchronize(stream_));
       TE_HIP_CHECK(hipMemcpy(nt, d_qr_, (size_t)n_classes_ * words * es, hipMemcpyDeviceToDevice));
     }
-    (void)hipFree(d_qr_);
+    device_free(d_qr_);
     d_qr_ = nt;
     qr_cap_ = want;
     drop_graphs();
@@ -105,7 +150,7 @@ void Batch::set_keep_measurement(bool on) {
       TE_HIP_CHECK(hipGetLastError());
     }
   } else {
-    (void)hipFree(d_lastmeas_);
+    device_free(d_lastmeas_);
     d_lastmeas_ = nullptr;
   }
   keep_meas_ = on;
@@ -171,19 +216,20 @@ StepParams Batch::base_params() const {
 Batch::~Batch() {
   if (live_.active) { try { live_stop(); } catch (...) {} }
   if (live_.zombie && live_.stream) (void)hipStreamSynchronize(live_.stream);   // (told to stop: it ends as soon as it starts)
+  live_release();
   (void)hipStreamSynchronize(stream_);
   drop_graphs();
   if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
-  (void)hipFree(d_qr_); (void)hipFree(d_rec_); (void)hipFree(d_rec_alt_); (void)hipFree(d_tbase_); (void)hipFree(d_nmbase_); (void)hipFree(d_cls_);
-  (void)hipFree(d_idx_); (void)hipFree(d_aos_); (void)hipFree(d_meas_); (void)hipFree(d_mask_); (void)hipFree(d_P0_);
-  (void)hipFree(d_gate_ring_); (void)hipFree(d_gate_sum_); (void)hipFree(d_gate_state_); (void)hipFree(d_gate_prev_);
-  (void)hipFree(d_dtper_); (void)hipFree(d_lastmeas_);
+  device_free(d_qr_); device_free(d_rec_); device_free(d_rec_alt_); device_free(d_tbase_); device_free(d_nmbase_); device_free(d_cls_);
+  device_free(d_idx_); device_free(d_aos_); device_free(d_meas_); device_free(d_mask_); device_free(d_P0_);
+  device_free(d_gate_ring_); device_free(d_gate_sum_); device_free(d_gate_state_); device_free(d_gate_prev_);
+  device_free(d_dtper_); device_free(d_lastmeas_);
   if (h_pin_) (void)hipHostFree(h_pin_);
   if (h_cache_) (void)hipHostFree(h_cache_);
-  (void)hipFree(d_state_scratch_);
+  device_free(d_state_scratch_);
   if (h_done_) (void)hipHostFree(h_done_);
   if (live_.h_posted) (void)hipHostFree(live_.h_posted);
-  (void)hipFree(live_.d_block);
+  device_free(live_.d_block);
   if (live_.stream) (void)hipStreamDestroy(live_.stream);
   if (live_.ready) (void)hipEventDestroy(live_.ready);
 }
@@ -261,13 +307,13 @@ void Batch::reserve(long n) {
     TE_HIP_CHECK(hipMemcpyAsync(cl, d_cls_, sizeof(int) * cap_, hipMemcpyDeviceToDevice, stream_));
   }
   TE_HIP_CHECK(hipStreamSynchronize(stream_));
-  (void)hipFree(d_rec_); (void)hipFree(d_tbase_); (void)hipFree(d_nmbase_); (void)hipFree(d_cls_);
-  (void)hipFree(d_rec_alt_); d_rec_alt_ = nullptr; alt_failed_ = false;   // re-created at the new capacity by the next A -> B tick
+  device_free(d_rec_); device_free(d_tbase_); device_free(d_nmbase_); device_free(d_cls_);
+  device_free(d_rec_alt_); d_rec_alt_ = nullptr; alt_failed_ = false;   // re-created at the new capacity by the next A -> B tick
   if (keep_meas_) {
     double* lm = nullptr;
     TE_HIP_CHECK(hipMalloc((void**)&lm, sizeof(double) * 7 * (size_t)want));
     if (d_lastmeas_ && cap_ > 0) TE_HIP_CHECK(hipMemcpy(lm, d_lastmeas_, sizeof(double) * 7 * (size_t)cap_, hipMemcpyDeviceToDevice));
-    (void)hipFree(d_lastmeas_);
+    device_free(d_lastmeas_);
     d_lastmeas_ = lm;
   }
   d_rec_ = rec; d_tbase_ = tb; d_nmbase_ = nm; d_cls_ = cl; cap_ = want;
@@ -278,7 +324,7 @@ void Batch::stage_reserve(long n) {
   if (n <= stage_cap_) return;
   const long want = std::max(n, stage_cap_ * 2);
   TE_HIP_CHECK(hipStreamSynchronize(stream_));
-  (void)hipFree(d_idx_); (void)hipFree(d_aos_); (void)hipFree(d_meas_); (void)hipFree(d_mask_); (void)hipFree(d_dtper_);
+  device_free(d_idx_); device_free(d_aos_); device_free(d_meas_); device_free(d_mask_); device_free(d_dtper_);
   TE_HIP_CHECK(hipMalloc((void**)&d_dtper_, sizeof(double) * want));
   TE_HIP_CHECK(hipMalloc((void**)&d_idx_, sizeof(int) * want));
   TE_HIP_CHECK(hipMalloc((void**)&d_aos_, sizeof(double) * 19 * want));
@@ -348,7 +394,7 @@ long Batch::append_now(long first, long count, const unsigned* ids, double t0, c
   const long p0_words = (P0_index ? P0_count : (per_target_P0 ? count : 1)) * (long)N * N;
   if (p0_words > P0_cap_) {
     TE_HIP_CHECK(hipStreamSynchronize(stream_));
-    (void)hipFree(d_P0_);
+    device_free(d_P0_);
     TE_HIP_CHECK(hipMalloc((void**)&d_P0_, sizeof(double) * p0_words));
     P0_cap_ = p0_words;
   }
@@ -573,6 +619,26 @@ void Batch::enqueue_tick(hipStream_t st, long s, double dt, const SeqSpec& q, bo
   }
 }
 
+bool Batch::population_ready() const {
+  return ops_->L.layout == LAYOUT_SEPARABLE_PACKED && n_classes_ == 1 && !keep_meas_ && ops_->fused_query;
+}
+
+StepParams Batch::tick_params(long s, double dt, const SeqSpec& q, bool query, const double* origin, double radius, bool ab) {
+  if (q.ring_ticks > 0) s %= q.ring_ticks;
+  const size_t es = elem_size();
+  StepParams p = base_params();
+  p.meas = q.meas_base ? static_cast<const char*>(q.meas_base) + (size_t)(s * q.tick_stride) * es : nullptr;
+  p.meas_ld = q.ld;
+  p.has_meas = q.has_base ? q.has_base + s * q.has_stride : nullptr;
+  p.dt = dt;
+  if (query) {
+    p.q_origin[0] = origin[0]; p.q_origin[1] = origin[1]; p.q_origin[2] = origin[2];
+    p.q_radius = radius; p.q_delta = q.delta_dev; p.q_pose = q.pose_dev;
+  }
+  if (ab && !query) p.rec_out = alt_records();
+  return p;
+}
+
 void Batch::account_sequence(long n_ticks, double dt, bool all_measured) {
   t_acc_ += dt * (double)n_ticks;
   if (all_measured) nm_acc_ += n_ticks;
@@ -614,6 +680,15 @@ void Batch::live_start(double dt, const void* meas_ring, long tick_stride, long 
     throw std::runtime_error("target_estimation_amd: live mode: " + std::to_string(n_) + " targets need " + std::to_string(waves) +
                              " resident wavefronts, the device holds " + std::to_string(cap) + " of this kernel");
   if (waves + 1 > cap) throw std::runtime_error("target_estimation_amd: live mode: no room for the relay wavefront");
+  // ... and next to the sessions that are resident already (other batches, other managers of this process): their grids hold
+  // their wave slots until they end, so a grid that only fits an empty device would start in part and never get its relay
+  const double share = (double)(waves + 1) / (double)cap;
+  if (!live_session_begin(share))
+    throw std::runtime_error("target_estimation_amd: live mode: " + std::to_string(n_) + " targets take " + std::to_string((int)(share * 100.0 + 0.5)) +
+                             " % of the device's resident wavefronts and the sessions already resident in this process take " +
+                             std::to_string((int)(live_sessions_share() * 100.0 + 0.5)) + " %: they do not fit the device together");
+  live_.share = share;   // counted from here on; every way out of the session gives it back (live_release)
+  try {
   if (!live_.h_posted) {
     char* h = nullptr;
     TE_HIP_CHECK(hipHostMalloc((void**)&h, 128, hipHostMallocMapped | hipHostMallocCoherent));
@@ -624,7 +699,7 @@ void Batch::live_start(double dt, const void* meas_ring, long tick_stride, long 
   }
   if (waves > live_.cap_waves) {
     TE_HIP_CHECK(hipStreamSynchronize(stream_));
-    (void)hipFree(live_.d_block);
+    device_free(live_.d_block);
     live_.d_block = nullptr;
     TE_HIP_CHECK(hipMalloc((void**)&live_.d_block, live_block_bytes(waves)));
     live_.cap_waves = waves;
@@ -644,6 +719,9 @@ void Batch::live_start(double dt, const void* meas_ring, long tick_stride, long 
     // they ask otherwise).
     int least = 0, greatest = 0;
     TE_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    if (const char* e = std::getenv("TE_LIVE_STREAM_PRIORITY")) {   // experiments only (tools/r4_regress.sh): 0 = normal, low = least
+      if (e[0] == 'l') greatest = least; else if (std::atoi(e) == 0) greatest = 0;
+    }
     TE_HIP_CHECK(hipStreamCreateWithPriority(&live_.stream, hipStreamNonBlocking, greatest));
   }
   if (!live_.ready) TE_HIP_CHECK(hipEventCreateWithFlags(&live_.ready, hipEventDisableTiming));
@@ -697,11 +775,20 @@ void Batch::live_start(double dt, const void* meas_ring, long tick_stride, long 
     const auto t_gone = std::chrono::steady_clock::now() + std::chrono::duration<double>(1.0);
     while (hipStreamQuery(live_.stream) == hipErrorNotReady && std::chrono::steady_clock::now() < t_gone) __builtin_ia32_pause();
     live_.zombie = hipStreamQuery(live_.stream) == hipErrorNotReady;   // still queued behind somebody else's kernel: flush() waits for it before anything touches the records
+    if (!live_.zombie) live_release();
     throw std::runtime_error("target_estimation_amd: live mode: the resident kernel did not start within " + std::to_string(kLiveStartTimeoutS) +
                              " s (its stream shares a hardware queue with another endless kernel -- more live batches than GPU_MAX_HW_QUEUES, or a "
                              "high-priority stream of the caller -- or the device is busy)");
   }
+  } catch (...) {
+    if (!live_.zombie) live_release();   // (a zombie still holds its place: flush() releases it once the kernel is gone)
+    throw;
+  }
   live_.active = true;
+}
+
+void Batch::live_release() {
+  if (live_.share > 0.0) { const double s = live_.share; live_.share = 0.0; live_session_ended(s); }
 }
 
 void Batch::live_set_pose_output(double* pose_soa_dev, long ld) {
@@ -736,7 +823,11 @@ long Batch::live_stop() {
   if (!live_.active) return 0;
   __atomic_store_n(live_.h_posted, (long long)live_.posted | kLiveStop, __ATOMIC_RELEASE);
   live_.active = false;     // whatever happens below, the session is over (flush() must not come back here)
-  TE_HIP_CHECK(hipStreamSynchronize(live_.stream));   // bounded: every wavefront drains the posted ticks, then sees the stop bit
+  {
+    const hipError_t e = hipStreamSynchronize(live_.stream);   // bounded: every wavefront drains the posted ticks, then sees the stop bit
+    live_release();                                          // the kernel is gone: its wave slots, and the frees that waited for it
+    TE_HIP_CHECK(e);
+  }
   // the relay's last word: the ticks EVERY wavefront served.  The host's stop, or the relay's own after a silent host, reaches
   // all workers through one device word, so they all stop at the same tick.
   const long mn = std::max(0L, (long)__atomic_load_n(live_.h_done, __ATOMIC_ACQUIRE));
@@ -863,7 +954,9 @@ static bool spin_wait_enabled() {
 void Batch::flush() {
   if (live_.zombie) {              // a resident kernel that never started in time: told to stop, it leaves the records as they are
     live_.zombie = false;
-    TE_HIP_CHECK(hipStreamSynchronize(live_.stream));
+    const hipError_t e = hipStreamSynchronize(live_.stream);
+    live_release();
+    TE_HIP_CHECK(e);
   }
   if (live_.active) live_stop();   // the records in HBM are stale while a live kernel holds the state
   flush_inits();                   // queued creations first: a queued step may be for one of them
@@ -1053,7 +1146,7 @@ void Batch::gate_reserve(int window) {
     TE_HIP_CHECK(hipMemcpyAsync(prev, d_gate_prev_, sizeof(double) * 7 * old_cap, hipMemcpyDeviceToDevice, stream_));
   }
   TE_HIP_CHECK(hipStreamSynchronize(stream_));
-  (void)hipFree(d_gate_ring_); (void)hipFree(d_gate_sum_); (void)hipFree(d_gate_state_); (void)hipFree(d_gate_prev_);
+  device_free(d_gate_ring_); device_free(d_gate_sum_); device_free(d_gate_state_); device_free(d_gate_prev_);
   d_gate_ring_ = ring; d_gate_sum_ = sum; d_gate_state_ = st; d_gate_prev_ = prev;
   gate_window_ = window;
   gate_cap_ = cap_;
@@ -1136,7 +1229,7 @@ void Batch::get_state(const int* slots, long n, double* x, double* P) {
   if (bx + bP <= kStateScratchKeep) {
     if (bx + bP > state_scratch_bytes_) {
       TE_HIP_CHECK(hipStreamSynchronize(stream_));
-      (void)hipFree(d_state_scratch_); d_state_scratch_ = nullptr; state_scratch_bytes_ = 0;
+      device_free(d_state_scratch_); d_state_scratch_ = nullptr; state_scratch_bytes_ = 0;
       const size_t want = std::max<size_t>(bx + bP, std::min<size_t>(2 * state_scratch_bytes_ + 4096, kStateScratchKeep));
       TE_HIP_CHECK(hipMalloc((void**)&d_state_scratch_, want));
       state_scratch_bytes_ = want;
@@ -1153,7 +1246,7 @@ void Batch::get_state(const int* slots, long n, double* x, double* P) {
   if (x) TE_HIP_CHECK(hipMemcpyAsync(x, dx, bx, hipMemcpyDeviceToHost, stream_));
   if (P) TE_HIP_CHECK(hipMemcpyAsync(P, dP, bP, hipMemcpyDeviceToHost, stream_));
   TE_HIP_CHECK(hipStreamSynchronize(stream_));
-  if (big) (void)hipFree(big);
+  if (big) device_free(big);
 }
 
 void Batch::set_state(const int* slots, long n, const double* x, const double* P, const double* unwrap) {
@@ -1169,7 +1262,7 @@ void Batch::set_state(const int* slots, long n, const double* x, const double* P
   ops_->set_state(d_rec_, slots ? d_idx_ : nullptr, n, dx, dP, du, stream_);
   TE_HIP_CHECK(hipGetLastError());
   TE_HIP_CHECK(hipStreamSynchronize(stream_));
-  (void)hipFree(dx); (void)hipFree(dP); (void)hipFree(du);
+  device_free(dx); device_free(dP); device_free(du);
 }
 
 long long Batch::n_measurements(long slot) {

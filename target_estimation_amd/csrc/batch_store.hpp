@@ -168,6 +168,12 @@ class Batch {
   // inside a stream capture: a recorded graph bakes its pointers), 0 = in place.
   void enqueue_tick(hipStream_t st, long s, double dt, const SeqSpec& spec, bool query, const double* origin, double radius,
                     bool reverse = false, bool ab = false);
+  // The same tick as launch parameters only, for the manager's one-launch population tick (kf_population.hpp): possible when
+  // population_ready() -- separable layout with packed groups, one (Q, R) class, no measured-pose rows to keep.  With ab the
+  // caller calls swap_records() once the launch is queued (and only if the returned parameters carry rec_out).
+  bool population_ready() const;
+  StepParams tick_params(long s, double dt, const SeqSpec& spec, bool query, const double* origin, double radius, bool ab);
+  void swap_records() { std::swap(d_rec_, d_rec_alt_); }
   void account_sequence(long n_ticks, double dt, bool all_measured);
   // identity of everything a recorded launch sequence refers to
   struct DevIdentity { const void* rec; const void* qr; const void* tbase; const void* nmbase; long n; };
@@ -342,7 +348,9 @@ class Batch {
     long posted = 0, max_ticks = 0;
     double dt = 0.0;
     bool all_measured = false;
+    double share = 0.0;              // > 0 while the session is counted among the process's resident sessions (hip_check.hpp)
   } live_;
+  void live_release();
 };
 
 }  // namespace te

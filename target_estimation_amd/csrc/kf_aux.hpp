@@ -326,10 +326,17 @@ struct IntersectArgs {
 // moving-average convergence gate (src/intersection_solver.cpp:42-104) for one target with state x:
 // quartic in delta from the (p, v, a) extrapolated by dq = t1 - t_, smallest real root, pose at
 // t1 + delta.  own = the query is at the target's own time (dq = 0, pose offset = delta itself).
-template <class M, typename T>
+// THROUGH: the results leave with system-scope write-through stores (the resident kernels: a consumer outside the kernel reads
+// them while it runs)
+template <class M, typename T, bool THROUGH = false>
 __device__ __forceinline__ void sphere_query(const T* x, bool own, double t1, double t, const double* origin, double radius,
                                              double* delta_out, double* pose_out /* [7] or null */) {
 #pragma clang fp contract(off)   // fused query, intersect kernel: the same roundings (te_device_math.hpp)
+  auto put = [](double* p, double v) {
+    if constexpr (THROUGH)
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else *p = v;
+  };
   T pose7[7], twist6[6], acc6[6];
   derive_outputs<M, T>(x, true, own ? (T)0 : (T)(t1 - t), pose7, twist6, acc6);
   const double px = (double)pose7[0] - origin[0], py = (double)pose7[1] - origin[1], pz = (double)pose7[2] - origin[2];
@@ -342,7 +349,7 @@ __device__ __forceinline__ void sphere_query(const T* x, bool own, double t1, do
   c[1] = 2 * (px * vx + py * vy + pz * vz);
   c[0] = px * px + py * py + pz * pz - radius * radius;
   const double d = first_crossing_quartic(c);   // leftmost real root if >= 0, else -1
-  *delta_out = d;
+  put(delta_out, d);
   if (pose_out) {
     double out[7] = {0, 0, 0, 0, 0, 0, 1};
     if (d > -1) {
@@ -350,7 +357,7 @@ __device__ __forceinline__ void sphere_query(const T* x, bool own, double t1, do
 #pragma unroll
       for (int k = 0; k < 7; ++k) out[k] = (double)pose7[k];
     }
-    for (int k = 0; k < 7; ++k) pose_out[k] = out[k];
+    for (int k = 0; k < 7; ++k) put(&pose_out[k], out[k]);
   }
 }
 

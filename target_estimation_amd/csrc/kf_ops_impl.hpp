@@ -11,6 +11,24 @@
 
 namespace te {
 
+// host-side launch parameters -> the kernels' argument block
+template <typename T>
+inline StepArgs<T> make_step_args(const StepParams& p) {
+  StepArgs<T> a;
+  a.rec = p.rec; a.rec_out = p.rec_out; a.qr = static_cast<const T*>(p.qr); a.cls = p.cls; a.n = p.n; a.idx = p.idx;
+  a.meas = static_cast<const T*>(p.meas); a.meas_ld = p.meas_ld; a.has_meas = p.has_meas;
+  a.dt_per = p.dt_per; a.dt = p.dt; a.t_base = p.t_base; a.nm_base = p.nm_base;
+  a.n_ticks = p.n_ticks; a.tick_stride = p.tick_stride; a.has_stride = p.has_stride;
+  a.q_origin[0] = p.q_origin[0]; a.q_origin[1] = p.q_origin[1]; a.q_origin[2] = p.q_origin[2];
+  a.q_radius = p.q_radius; a.q_delta = p.q_delta; a.q_pose = p.q_pose;
+  a.reverse = p.reverse; a.nt_meas = p.nt_meas;
+  a.o_pose = p.o_pose; a.o_twist = p.o_twist; a.o_acc = p.o_acc; a.done_flag = p.done_flag; a.done_seq = p.done_seq;
+  a.live_posted = p.live_posted; a.live_mirror = p.live_mirror; a.live_progress = p.live_progress; a.live_done = p.live_done;
+  a.live_ring = p.live_ring; a.live_first = p.live_first;
+  a.live_spin_limit = p.live_spin_limit; a.live_idle_ticks = p.live_idle_ticks; a.live_flags = p.live_flags; a.live_pose = p.live_pose; a.live_pose_ld = p.live_pose_ld;
+  return a;
+}
+
 template <class M, typename T, int G, int LAYOUT = LAYOUT_FULL>
 struct OpsImpl {
   using C = Cfg<M, T, G, LAYOUT>;
@@ -37,18 +55,7 @@ struct OpsImpl {
   }
   static void step(const StepParams& p, hipStream_t s) {
     if (p.n <= 0) return;
-    StepArgs<T> a;
-    a.rec = p.rec; a.rec_out = p.rec_out; a.qr = static_cast<const T*>(p.qr); a.cls = p.cls; a.n = p.n; a.idx = p.idx;
-    a.meas = static_cast<const T*>(p.meas); a.meas_ld = p.meas_ld; a.has_meas = p.has_meas;
-    a.dt_per = p.dt_per; a.dt = p.dt; a.t_base = p.t_base; a.nm_base = p.nm_base;
-    a.n_ticks = p.n_ticks; a.tick_stride = p.tick_stride; a.has_stride = p.has_stride;
-    a.q_origin[0] = p.q_origin[0]; a.q_origin[1] = p.q_origin[1]; a.q_origin[2] = p.q_origin[2];
-    a.q_radius = p.q_radius; a.q_delta = p.q_delta; a.q_pose = p.q_pose;
-    a.reverse = p.reverse;
-    a.o_pose = p.o_pose; a.o_twist = p.o_twist; a.o_acc = p.o_acc; a.done_flag = p.done_flag; a.done_seq = p.done_seq;
-    a.live_posted = p.live_posted; a.live_mirror = p.live_mirror; a.live_progress = p.live_progress; a.live_done = p.live_done;
-    a.live_ring = p.live_ring; a.live_first = p.live_first;
-    a.live_spin_limit = p.live_spin_limit; a.live_idle_ticks = p.live_idle_ticks; a.live_flags = p.live_flags; a.live_pose = p.live_pose; a.live_pose_ld = p.live_pose_ld;
+    StepArgs<T> a = make_step_args<T>(p);
     if (p.live_posted) {   // resident launch: one wavefront per workgroup, every workgroup resident (Batch::live_start checked the capacity)
       if constexpr (kHasLive) {
         if (p.idx || p.cls || p.rec_out || !p.live_progress || !p.live_mirror || !p.live_done || p.live_ring <= 0 || p.n_ticks < 1)

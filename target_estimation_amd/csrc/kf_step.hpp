@@ -101,7 +101,7 @@ struct StepArgs {
   long live_first;
   unsigned live_spin_limit;
   unsigned long long live_idle_ticks;   // the idle limit on the device's wall clock (0: count relay rounds instead, live_spin_limit)
-  int live_flags;   // (reserved for experiments, TE_LIVE_FLAGS; unused)
+  int live_flags;   // experiments (TE_LIVE_FLAGS): 8 = relay scans slowly always, 16 = kLiveRelaxed (round 3's relaxed hand-offs)
   // live_pose (or null): SoA [7][live_pose_ld] doubles in device memory that receives the estimated pose of every target after
   // every tick (what the reference's node publishes every tick, src/target_manager_ros.cpp:78-87), written THROUGH the caches
   // before the tick's progress word, so that a copy engine that reads it after `done` reached the tick sees that tick's poses
@@ -122,13 +122,33 @@ __device__ __forceinline__ long long wave_uniform_ll(long long v) {
 // Every 4096th poll (a millisecond or two of waiting) the wavefront also looks at the host's own word, over PCIe: a stop there with
 // nothing left to serve ends it even when the relay is not there to pass it on -- a grid that never became fully resident, which
 // Batch::live_start gives up on (the relay is its LAST workgroup).  A busy session never waits that long between ticks.
-__device__ __forceinline__ bool live_wait_tick(const long long* mirror, const long long* host_posted, long long need, unsigned limit, long long& seen, int lane) {
-  if ((seen & kLiveCount) >= need) return true;
+//
+// Ordering of the hand-offs (kLiveRelaxed in live_flags = the round-3 form, relaxed everywhere, kept for the before / after
+// measurement in profiles/r04_live_ordering.txt):
+//   host      ring entries, then posted        store RELEASE                       (Batch::live_post)
+//   relay     posted                           load  ACQUIRE  system
+//             mirror                           store RELEASE  agent
+//   worker    mirror                           load  relaxed while polling, then an ACQUIRE fence (agent) once the tick is admitted,
+//                                              before the tick's measurement loads
+//             outputs of the tick (poses, query results): system-scope write-through stores, waited for (vmcnt 0)
+//             progress                         store RELEASE  agent
+//   relay     progress scan                    loads relaxed, then an ACQUIRE fence (agent) behind the scan
+//             done                             store RELEASE  system
+//   host      done                             load  ACQUIRE                        (Batch::live_done)
+constexpr int kLiveRelaxed = 16;
+// single edges switched off (measurement only): worker's acquire fence, worker's progress release, relay's acquire fence,
+// relay's release of `done`, relay's release fence ahead of the mirror words
+constexpr int kLiveNoWorkerAcq = 32, kLiveNoWorkerRel = 64, kLiveNoRelayAcq = 128, kLiveNoDoneRel = 256, kLiveNoMirrorRel = 512;
+__device__ __forceinline__ bool live_wait_tick(const long long* mirror, const long long* host_posted, long long need, unsigned limit, long long& seen, int lane, int flags = 0) {
+  if ((seen & kLiveCount) >= need) return true;   // (admitted by an earlier poll: its fence covered this tick's entries too)
   for (unsigned spins = 0;; ++spins) {
     long long v = 0;
     if (lane == 0) v = __hip_atomic_load(mirror, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     seen = wave_uniform_ll(v);
-    if ((seen & kLiveCount) >= need) return true;
+    if ((seen & kLiveCount) >= need) {
+      if (!(flags & (kLiveRelaxed | kLiveNoWorkerAcq))) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      return true;
+    }
     if (seen < 0) return false;        // stop, and every posted tick is done
     if (spins >= limit) return false;  // backstop (the relay stops the session long before)
     if ((spins & 4095u) == 4095u) {
@@ -159,7 +179,7 @@ __device__ __forceinline__ void live_relay(const long long* posted, long long* m
     // the round costs the longer of the two round trips, not their sum.  The scan keeps up to 32 independent loads in flight per
     // lane (one after the other, 25 dependent round trips made a 1563-wavefront round 17 us long).
     long long v = 0;
-    if (lane == 0) v = __hip_atomic_load(posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane == 0) v = __hip_atomic_load(posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (its acquire: the fence behind the scan)
     int mn = 0x7fffffff;
     for (long w0 = 0; w0 < waves; w0 += kLiveScan) {
       int p[32];
@@ -175,6 +195,8 @@ __device__ __forceinline__ void live_relay(const long long* posted, long long* m
       for (int k = 0; k < 32; ++k) mn = p[k] < mn ? p[k] : mn;
     }
     v = wave_uniform_ll(v);
+    // one acquire fence for everything this round has read: the host's word (system) and the workers' progress words (agent)
+    if (!(flags & (kLiveRelaxed | kLiveNoRelayAcq))) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       const int o = __shfl_xor(mn, off, 64);
@@ -182,7 +204,10 @@ __device__ __forceinline__ void live_relay(const long long* posted, long long* m
     }
     const bool progressed = mn != last_done;
     if (progressed) {
-      if (lane == 0) __hip_atomic_store(done, mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // one PCIe write per change
+      if (lane == 0) {   // one PCIe write per change
+        if (flags & (kLiveRelaxed | kLiveNoDoneRel)) __hip_atomic_store(done, mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else __hip_atomic_store(done, mn, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       last_done = mn;
     }
     const bool caught_up = (long long)mn >= (last & kLiveCount);
@@ -191,6 +216,7 @@ __device__ __forceinline__ void live_relay(const long long* posted, long long* m
     else if (caught_up && idle_over) v = last | kLiveStop;      // everything served and a silent host: stop at what was posted
     if (v != last) {
       const long groups = (waves + kLiveGroup - 1) / kLiveGroup;
+      if (!(flags & (kLiveRelaxed | kLiveNoMirrorRel))) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // one release for all copies of the word
       for (long g = lane; g < groups; g += 64)
         __hip_atomic_store(&mirror[g * kLiveMirrorStride], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       last = v;

@@ -92,12 +92,51 @@ constexpr int sep_min_waves() {
   return (PERQR && M::TYPE == ANGULAR_RATES && sizeof(T) == 8 && LAYOUT == LAYOUT_SEPARABLE_PACKED) ? 3 : 1;
 }
 
+// Resident kernels keep the whole record in registers between ticks, and the capacity of the mode is the register file.  For
+// the fp64 angular models that is not enough (angular_rates: 57 words = 114 registers of state under an fp64 atan2 / asin chain
+// -> 262, one wavefront per SIMD, 49 152 targets): part of the record is PARKED in the wavefront's LDS between its uses --
+// every lane its own column, word-interleaved (conflict-free ds_read/write_b64), read when its chain's turn comes and written
+// back behind it.  live_park_chains<M, T>() = how many [p v (a)] chains park their covariance words (P) / their state words (x).
+template <class M, typename T> constexpr int live_park_p_chains() {
+#ifdef TE_PARK_P
+  return TE_PARK_P;
+#else
+  return sizeof(T) == 8 && M::TYPE == ANGULAR_RATES ? 4 : sizeof(T) == 8 && M::TYPE == ANGULAR_VELOCITIES ? 3 : 0;
+#endif
+}
+template <class M, typename T> constexpr int live_park_x_chains() {
+#ifdef TE_PARK_X
+  return TE_PARK_X;
+#else
+  return sizeof(T) == 8 && M::TYPE == ANGULAR_VELOCITIES ? 3 : 0;
+#endif
+}
+template <class C, class M, typename T> struct LivePark {
+  static constexpr int NLIN = M::EKF ? 3 : C::K, LB = M::EKF ? 2 : C::NB, STRIDE = M::EKF ? 6 : C::K;
+  struct Table { int v[C::RW]; int count; };
+  static constexpr Table make() {
+    Table t{};
+    for (int w = 0; w < C::RW; ++w) t.v[w] = -1;
+    int k = 0;
+    for (int i = 0; i < NLIN && i < live_park_p_chains<M, T>(); ++i)
+      for (int b = 0; b < LB; ++b)
+        for (int c = b; c < LB; ++c) t.v[C::PWORD.v[i + STRIDE * b][i + STRIDE * c]] = k++;
+    for (int i = 0; i < NLIN && i < live_park_x_chains<M, T>(); ++i)
+      for (int b = 0; b < LB; ++b) t.v[C::X_OFF + i + STRIDE * b] = k++;
+    t.count = k;
+    return t;
+  }
+  static constexpr Table SLOT = make();
+};
+
 // LIVE: a resident launch (StepArgs::live_*): the tick loop of FUSED with a wait for the host's doorbell in front of every tick
 // and a progress word behind it (1), optionally with the per-tick sphere query and pose output (2: more registers, so fewer
 // resident targets).  Same arithmetic per tick, same results as single ticks.
 // AB: an A -> B tick (StepArgs::rec_out), its own instantiation (see kf_step_kernel).
+// The step of one wavefront's targets: `wg` = index of the wavefront among those of the launch (of the BATCH, in a population
+// launch: kf_step_population_kernel below), lane = its lane.
 template <class M, typename T, int LAYOUT, bool INDEXED, bool FUSED = false, bool QUERY = false, bool PERQR = false, int LIVE = 0, bool AB = false>
-__global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR, LIVE>())) kf_step_sep_kernel(const StepArgs<T> a) {
+__device__ __forceinline__ void sep_step_wave(const StepArgs<T>& a, long wg, const int lane) {
   static_assert(!AB || (!INDEXED && !FUSED && !QUERY && !LIVE), "A -> B ticks are dense single-tick launches without the fused query");
   static_assert(!(QUERY && (INDEXED || FUSED)), "the fused query is for dense single-tick launches");
   static_assert(!(PERQR && (FUSED || QUERY)), "per-class Q/R: single-tick launches without the fused query");
@@ -107,8 +146,6 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR, LIVE>
   constexpr int N = C::N, K = C::K, NB = C::NB, TPW = C::TPW;
   using F = Mth<T>;
 
-  const int lane = threadIdx.x & 63;
-  long wg = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if constexpr (LIVE) {   // the workgroup behind the last worker is the relay between the host's words and the device's
     const long workers = (a.n + TPW - 1) / TPW;
     if (wg == workers) {
@@ -137,18 +174,59 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR, LIVE>
   }
   char* tb = a.rec + tile * C::TILE_BYTES;
   T mem[C::RW];
-  if (valid) {
+  // LIVE: the parked part of the record (LivePark) lives in the wavefront's LDS for the whole session
+  using Park = LivePark<C, M, T>;
+  constexpr int NPARK = (LIVE != 0 && C::SEPPK) ? Park::SLOT.count : 0;
+  __shared__ T park_lds[NPARK > 0 ? NPARK * 64 : 1];
+  if constexpr (NPARK > 0) {
+    // the record goes to its two homes chunk by chunk, a few loads in flight at a time: loaded whole (load_record) it would
+    // itself be the register peak of the kernel.  Once per session: its speed does not matter.
+    static_assert(C::REM2 == 0, "parked records: 16-byte chunks and a one-word tail");
+    using V = typename Vec16<T>::type;
+#pragma unroll
+    for (int c = 0; c < C::NC; ++c) {
+      V v{};
+      if (valid) v = *reinterpret_cast<const V*>(tb + (long)c * C::LPT * 16 + (long)lt * 16);
+      T w2[C::VW];
+      __builtin_memcpy(w2, &v, 16);
+#pragma unroll
+      for (int k = 0; k < C::VW; ++k) {
+        const int w = c * C::VW + k;
+        if (Park::SLOT.v[w] >= 0) park_lds[Park::SLOT.v[w] * 64 + lane] = w2[k];
+        else mem[w] = w2[k];
+      }
+      if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (C::REM1) {
+      const T v = valid ? *reinterpret_cast<const T*>(tb + C::TAIL1_OFF + (long)lt * (long)sizeof(T)) : T(0);
+      if (Park::SLOT.v[C::RW - 1] >= 0) park_lds[Park::SLOT.v[C::RW - 1] * 64 + lane] = v;
+      else mem[C::RW - 1] = v;
+    }
+  } else if (valid) {
     load_record<C, T>(tb, lt, mem);
   } else {
 #pragma unroll
     for (int w = 0; w < C::RW; ++w) mem[w] = 0;
   }
+  auto RD = [&](int w) -> T {
+    if (NPARK > 0 && Park::SLOT.v[w] >= 0) return park_lds[Park::SLOT.v[w] * 64 + lane];
+    return mem[w];
+  };
+  auto WR = [&](int w, T v) {
+    if (NPARK > 0 && Park::SLOT.v[w] >= 0) park_lds[Park::SLOT.v[w] * 64 + lane] = v;
+    else mem[w] = v;
+  };
   double dtd = a.dt;
   if constexpr (INDEXED) {
     if (a.dt_per && valid) dtd = a.dt_per[entry];
   }
   const T dt = (T)dtd;
-  const T* Qm = a.qr;
+  // The one (Q, R) row of a one-class batch, through the CONSTANT address space: uniform and never written while a step kernel
+  // runs, so every read is a scalar load wherever it sits.  As a plain global pointer it stops being one behind the resident
+  // loop's atomics (the compiler can no longer prove that nothing clobbers it): the fp64 angular kernels, whose 60 words do not
+  // fit the scalar registers ahead of the loop, fetched them with vector loads every tick -- 120 vector registers.
+  typedef const T __attribute__((address_space(4))) ConstT;
+  ConstT* Qm = (ConstT*)a.qr;
   // PERQR: when every target of the wavefront belongs to ONE class -- the usual case, classes arrive in runs -- the row is
   // read through the scalar cache like the single (Q, R) of a one-class batch (Qu, a uniform address); only a wavefront
   // that mixes classes pays for per-lane gathers of its rows.
@@ -207,7 +285,7 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR, LIVE>
   long slot_tick = tick;
   if constexpr (LIVE) {
     // (the worker's own limit is a backstop far behind the relay's: a relay round is a PCIe read + a scan, a worker poll an L2 hit)
-    if (!live_wait_tick(a.live_mirror + (wave_id / kLiveGroup) * kLiveMirrorStride, a.live_posted, (long long)tick + 1, a.live_spin_limit < 0x07ffffffu ? 32u * a.live_spin_limit + 10000000u : 0xffffffffu, live_seen, lane)) break;
+    if (!live_wait_tick(a.live_mirror + (wave_id / kLiveGroup) * kLiveMirrorStride, a.live_posted, (long long)tick + 1, a.live_spin_limit < 0x07000000u ? 32u * a.live_spin_limit + 10000000u : 0xffffffffu, live_seen, lane, a.live_flags)) break;
     slot_tick = (a.live_first + tick) % a.live_ring;
   }
   const T* meas_t = a.meas ? a.meas + slot_tick * a.tick_stride : nullptr;
@@ -267,11 +345,13 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR, LIVE>
       q[2] = ymeas[5];
       q[3] = ymeas[6];
       quat_normalize(q);
-      quat_to_rpy(q, mrpy);
+      quat_to_rpy<T, (LIVE != 0 && sizeof(T) == 8)>(q, mrpy);
     }
   }
 #define XW_(r) mem[C::X_OFF + (r)]
 #define UWW_(s) mem[C::UW_OFF + (s)]
+#define XR_(r) RD(C::X_OFF + (r))
+#define XS_(r, v) WR(C::X_OFF + (r), (v))
 
   // ---- the [p v (a)] chains
 #pragma unroll
@@ -280,9 +360,9 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR, LIVE>
     T r_meas = T(0);   // (every path assigns it; the per-class branches hide that from the compiler)
 #pragma unroll
     for (int b = 0; b < LB; ++b) {
-      xs[b] = XW_(i + STRIDE * b);
+      xs[b] = XR_(i + STRIDE * b);
 #pragma unroll
-      for (int c = 0; c < LB; ++c) Pb[b][c] = mem[C::PWORD.v[i + STRIDE * b][i + STRIDE * c]];
+      for (int c = 0; c < LB; ++c) Pb[b][c] = RD(C::PWORD.v[i + STRIDE * b][i + STRIDE * c]);
     }
     if constexpr (HOIST_QR) {
 #pragma unroll
@@ -291,8 +371,8 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR, LIVE>
         for (int c = 0; c < LB; ++c) Qb[b][c] = Qlin[i][b][c];
       r_meas = Rlin[i];
     } else {
-      const T* Qsrc = PERQR ? lane_row() : Qm;
       if constexpr (PERQR) {
+        const T* Qsrc = lane_row();
         if (cls_uniform) {   // wave-uniform branch: scalar loads from the one row
 #pragma unroll
           for (int b = 0; b < LB; ++b)
@@ -301,13 +381,19 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR, LIVE>
           r_meas = Qu[C::RWORD.v[i][i]];
           Qsrc = nullptr;
         }
-      }
-      if (Qsrc != nullptr) {
+        if (Qsrc != nullptr) {
+#pragma unroll
+          for (int b = 0; b < LB; ++b)
+#pragma unroll
+            for (int c = 0; c < LB; ++c) Qb[b][c] = Qsrc[C::QWORD.v[i + STRIDE * b][i + STRIDE * c]];
+          r_meas = Qsrc[C::RWORD.v[i][i]];
+        }
+      } else {
 #pragma unroll
         for (int b = 0; b < LB; ++b)
 #pragma unroll
-          for (int c = 0; c < LB; ++c) Qb[b][c] = Qsrc[C::QWORD.v[i + STRIDE * b][i + STRIDE * c]];
-        r_meas = Qsrc[C::RWORD.v[i][i]];
+          for (int c = 0; c < LB; ++c) Qb[b][c] = Qm[C::QWORD.v[i + STRIDE * b][i + STRIDE * c]];
+        r_meas = Qm[C::RWORD.v[i][i]];
       }
     }
     T y = 0;
@@ -322,10 +408,11 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR, LIVE>
     sep_linear_axis<LB, T>(xs, Pb, Qb, r_meas, dt, has, y);
 #pragma unroll
     for (int b = 0; b < LB; ++b) {
-      XW_(i + STRIDE * b) = xs[b];
+      XS_(i + STRIDE * b, xs[b]);
 #pragma unroll
-      for (int c = (C::SEPPK ? b : 0); c < LB; ++c) mem[C::PWORD.v[i + STRIDE * b][i + STRIDE * c]] = Pb[b][c];
+      for (int c = (C::SEPPK ? b : 0); c < LB; ++c) WR(C::PWORD.v[i + STRIDE * b][i + STRIDE * c], Pb[b][c]);
     }
+    if constexpr (NPARK > 0) __builtin_amdgcn_sched_barrier(0);   // a parked chain's words are read when its turn comes, not ahead of it
   }
 
   // ---- EKF attitude group: local rows 0..2 = rpy (global 3..5), 3..5 = omega (global 9..11)
@@ -411,13 +498,18 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR, LIVE>
 #pragma unroll
         for (int c = 0; c < 6; ++c) qrow[c] = Qatt[r][c];
       } else {
-        const T* Qsrc = PERQR ? lane_row() : Qm;
-        if (PERQR && cls_uniform) {
+        if constexpr (PERQR) {
+          if (cls_uniform) {
 #pragma unroll
-          for (int c = 0; c < 6; ++c) qrow[c] = Qu[C::QWORD.v[GR[r]][GR[c]]];
+            for (int c = 0; c < 6; ++c) qrow[c] = Qu[C::QWORD.v[GR[r]][GR[c]]];
+          } else {
+            const T* Qsrc = lane_row();
+#pragma unroll
+            for (int c = 0; c < 6; ++c) qrow[c] = Qsrc[C::QWORD.v[GR[r]][GR[c]]];
+          }
         } else {
 #pragma unroll
-          for (int c = 0; c < 6; ++c) qrow[c] = Qsrc[C::QWORD.v[GR[r]][GR[c]]];
+          for (int c = 0; c < 6; ++c) qrow[c] = Qm[C::QWORD.v[GR[r]][GR[c]]];
         }
       }
 #pragma unroll
@@ -431,8 +523,8 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR, LIVE>
         for (int c = 0; c < 3; ++c) {
           T rrc;
           if constexpr (HOIST_QR) rrc = Ratt[r][c];
-          else if (PERQR && cls_uniform) rrc = Qu[C::RWORD.v[3 + r][3 + c]];
-          else rrc = (PERQR ? lane_row() : Qm)[C::RWORD.v[3 + r][3 + c]];
+          else if constexpr (PERQR) rrc = cls_uniform ? Qu[C::RWORD.v[3 + r][3 + c]] : lane_row()[C::RWORD.v[3 + r][3 + c]];
+          else rrc = Qm[C::RWORD.v[3 + r][3 + c]];
           S[r][c] = Pr[r][c] + rrc;
         }
 #pragma unroll
@@ -504,30 +596,54 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR, LIVE>
     if (a.q_delta != nullptr && valid) {
       T xq[N];
 #pragma unroll
-      for (int r = 0; r < N; ++r) xq[r] = XW_(r);
-      sphere_query<M, T>(xq, true, 0.0, 0.0, a.q_origin, a.q_radius, &a.q_delta[entry], a.q_pose ? &a.q_pose[entry * 7] : nullptr);
+      for (int r = 0; r < N; ++r) xq[r] = XR_(r);
+      // (written THROUGH the caches like the poses below: a consumer on another stream or a copy engine that reads them once
+      // `done` has reached the tick must see this tick's results, not what an XCD's L2 still holds)
+      sphere_query<M, T, true>(xq, true, 0.0, 0.0, a.q_origin, a.q_radius, &a.q_delta[entry], a.q_pose ? &a.q_pose[entry * 7] : nullptr);
     }
     if (a.live_pose != nullptr) {   // the tick's estimated poses for a consumer outside the kernel (StepArgs::live_pose)
       if (valid) {
         T xq[N], pose7[7], twist6[6], acc6[6];
 #pragma unroll
-        for (int r = 0; r < N; ++r) xq[r] = XW_(r);
+        for (int r = 0; r < N; ++r) xq[r] = XR_(r);
         derive_outputs<M, T>(xq, false, (T)0, pose7, twist6, acc6);
 #pragma unroll
         for (int c = 0; c < 7; ++c)   // system-scope stores: written through to memory, 512 contiguous bytes per wavefront and row
           __hip_atomic_store(reinterpret_cast<unsigned long long*>(&a.live_pose[(long)c * a.live_pose_ld + entry]),
                              (unsigned long long)__double_as_longlong((double)pose7[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the rows have left before the progress word says so
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tick's outputs have left before the progress word says so
   }
   if constexpr (LIVE) {
     // tick `tick` is done (state in registers): a word in device memory for the relay
-    if (lane == 0) __hip_atomic_store(&a.live_progress[wave_id], tick + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) {
+      if (a.live_flags & (kLiveRelaxed | kLiveNoWorkerRel)) __hip_atomic_store(&a.live_progress[wave_id], tick + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else __hip_atomic_store(&a.live_progress[wave_id], tick + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   }  // tick loop
   if (valid) {
-    if constexpr (AB) store_record<C, T, false, true>(a.rec_out + tile * C::TILE_BYTES, lt, mem);   // A -> B tick (StepArgs::rec_out)
+    if constexpr (NPARK > 0) {   // the reverse of the session's first lines: chunk by chunk from the record's two homes
+      using V = typename Vec16<T>::type;
+#pragma unroll
+      for (int c = 0; c < C::NC; ++c) {
+        T w2[C::VW];
+#pragma unroll
+        for (int k = 0; k < C::VW; ++k) {
+          const int w = c * C::VW + k;
+          w2[k] = Park::SLOT.v[w] >= 0 ? park_lds[Park::SLOT.v[w] * 64 + lane] : mem[w];
+        }
+        V v;
+        __builtin_memcpy(&v, w2, 16);
+        *reinterpret_cast<V*>(tb + (long)c * C::LPT * 16 + (long)lt * 16) = v;
+        if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (C::REM1)
+        *reinterpret_cast<T*>(tb + C::TAIL1_OFF + (long)lt * (long)sizeof(T)) =
+            Park::SLOT.v[C::RW - 1] >= 0 ? park_lds[Park::SLOT.v[C::RW - 1] * 64 + lane] : mem[C::RW - 1];
+    }
+    else if constexpr (AB) store_record<C, T, false, true>(a.rec_out + tile * C::TILE_BYTES, lt, mem);   // A -> B tick (StepArgs::rec_out)
     else store_record<C, T>(tb, lt, mem);
     if constexpr (QUERY) {
       T xq[N];
@@ -556,6 +672,41 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR, LIVE>
   }
 #undef XW_
 #undef UWW_
+#undef XR_
+#undef XS_
+}
+
+template <class M, typename T, int LAYOUT, bool INDEXED, bool FUSED = false, bool QUERY = false, bool PERQR = false, int LIVE = 0, bool AB = false>
+__global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR, LIVE>())) kf_step_sep_kernel(const StepArgs<T> a) {
+  sep_step_wave<M, T, LAYOUT, INDEXED, FUSED, QUERY, PERQR, LIVE, AB>(a, (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), (int)(threadIdx.x & 63));
+}
+
+// ---- one launch for the whole population of a manager ------------------------------------------------------------------------
+// A manager with several motion models has one batch per model; their ticks are independent, and as separate launches they only
+// overlap if the runtime happens to put their streams on hardware queues that the device runs side by side.  That is not a
+// property to build on: measured (profiles/r04_queue_pipes.txt), the two branches of a recorded tick ran 2-3x slower as soon as
+// the process owned a fifth hardware queue, whoever created it.  Here the tick of ALL batches is one grid: the first end[0]
+// workgroups step the angular-rates batch, the next ones the angular-velocities batch, and so on in the order of the
+// reference's enum (target_manager.hpp:38) -- the heaviest model first.  Each part is exactly kf_step_sep_kernel's arithmetic
+// (sep_step_wave) on its own StepArgs; an absent model has end[k] == end[k - 1].
+template <typename T>
+struct PopulationArgs {
+  StepArgs<T> part[4];     // indexed by ModelType
+  unsigned end[4];         // first workgroup BEHIND part k
+  int reverse_blocks;      // zig-zag over the whole population: walk the workgroups (parts and their tiles) last to first
+};
+
+template <typename T, bool QUERY, bool AB>
+__global__ void __launch_bounds__(256) kf_step_population_kernel(const PopulationArgs<T> p) {
+  const int lane = (int)(threadIdx.x & 63);
+  const unsigned wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  unsigned b = blockIdx.x;
+  if (p.reverse_blocks) b = gridDim.x - 1 - b;
+  constexpr int L = LAYOUT_SEPARABLE_PACKED;
+  if (b < p.end[0]) sep_step_wave<ModelAR, T, L, false, false, QUERY, false, 0, AB>(p.part[0], (long)b * wpb + wave, lane);
+  else if (b < p.end[1]) sep_step_wave<ModelAV, T, L, false, false, QUERY, false, 0, AB>(p.part[1], (long)(b - p.end[0]) * wpb + wave, lane);
+  else if (b < p.end[2]) sep_step_wave<ModelUA, T, L, false, false, QUERY, false, 0, AB>(p.part[2], (long)(b - p.end[1]) * wpb + wave, lane);
+  else sep_step_wave<ModelUV, T, L, false, false, QUERY, false, 0, AB>(p.part[3], (long)(b - p.end[2]) * wpb + wave, lane);
 }
 
 }  // namespace te

@@ -78,7 +78,7 @@ PoseComm::~PoseComm() {
   if (ready_) (void)hipEventDestroy(ready_);
   if (start_) (void)hipEventDestroy(start_);
   if (done_) (void)hipEventDestroy(done_);
-  (void)hipFree(send_);
+  device_free(send_);
 }
 
 void PoseComm::begin(TargetManager* m, int root, const long* counts, double* recv_dev) {
@@ -88,7 +88,7 @@ void PoseComm::begin(TargetManager* m, int root, const long* counts, double* rec
   if (rank_ == root && !recv_dev && mine > 0) throw std::invalid_argument("target_estimation_amd: gather: the root needs a receive buffer");
   if (mine > send_cap_ && rank_ != root) {
     if (in_flight_) TE_HIP_CHECK(hipEventSynchronize(done_));
-    (void)hipFree(send_);
+    device_free(send_);
     send_ = nullptr; send_cap_ = 0;
     TE_HIP_CHECK(hipMalloc((void**)&send_, sizeof(double) * 7 * mine));
     send_cap_ = mine;

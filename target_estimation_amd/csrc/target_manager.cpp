@@ -1,5 +1,6 @@
 // target_manager.cpp -- see target_manager.hpp.
 #include "target_manager.hpp"
+#include "kf_population.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -38,9 +39,9 @@ TargetManager::TargetManager(const std::string& file, int dtype, int lanes_per_t
 
 void TargetManager::devIdsFree() {
   DevIds& d = dev_ids_;
-  (void)hipFree(d.keys); (void)hipFree(d.vals); (void)hipFree(d.seen);
-  (void)hipFree(d.ids); (void)hipFree(d.loc); (void)hipFree(d.idx); (void)hipFree(d.aos); (void)hipFree(d.soa);
-  (void)hipFree(d.mask); (void)hipFree(d.found); (void)hipFree(d.out); (void)hipFree(d.counters);
+  device_free(d.keys); device_free(d.vals); device_free(d.seen);
+  device_free(d.ids); device_free(d.loc); device_free(d.idx); device_free(d.aos); device_free(d.soa);
+  device_free(d.mask); device_free(d.found); device_free(d.out); device_free(d.counters);
   if (d.h_counters) (void)hipHostFree(d.h_counters);
   d = DevIds();
 }
@@ -54,8 +55,8 @@ void TargetManager::devIdsReserve(long n) {
   if (n <= d.cap) return;
   const long want = std::max(n, d.cap * 2);
   TE_HIP_CHECK(hipStreamSynchronize(stream_));
-  (void)hipFree(d.ids); (void)hipFree(d.loc); (void)hipFree(d.idx); (void)hipFree(d.aos); (void)hipFree(d.soa);
-  (void)hipFree(d.mask); (void)hipFree(d.found); (void)hipFree(d.out);
+  device_free(d.ids); device_free(d.loc); device_free(d.idx); device_free(d.aos); device_free(d.soa);
+  device_free(d.mask); device_free(d.found); device_free(d.out);
   TE_HIP_CHECK(hipMalloc((void**)&d.ids, sizeof(unsigned) * want));
   TE_HIP_CHECK(hipMalloc((void**)&d.loc, sizeof(int) * want));
   TE_HIP_CHECK(hipMalloc((void**)&d.idx, sizeof(int) * want));
@@ -75,7 +76,7 @@ void TargetManager::devIdsRebuild() {
   if (log2cap > 31) throw std::runtime_error("target_estimation_amd: too many targets for the device id table");
   if (log2cap != d.log2cap) {
     TE_HIP_CHECK(hipStreamSynchronize(stream_));
-    (void)hipFree(d.keys); (void)hipFree(d.vals); (void)hipFree(d.seen);
+    device_free(d.keys); device_free(d.vals); device_free(d.seen);
     const size_t cap = size_t(1) << log2cap;
     TE_HIP_CHECK(hipMalloc((void**)&d.keys, sizeof(unsigned) * cap));
     TE_HIP_CHECK(hipMalloc((void**)&d.vals, sizeof(unsigned) * cap));
@@ -1099,6 +1100,44 @@ void TargetManager::dropSeqGraphs() {
   seq_graphs_.clear();
 }
 
+// Can the tick of all batches be ONE launch?  At least two non-empty batches, every one of them a one-class batch in the
+// separable layout with packed groups (the automatic choice for the shipped models) -- then there is at most one batch per motion
+// model.  TE_POPULATION_TICK=0 keeps the launch per batch (experiments, and the comparison in profiles/).
+bool TargetManager::populationTick() const {
+  static const bool on = [] { const char* e = std::getenv("TE_POPULATION_TICK"); return !(e && e[0] == '0'); }();
+  if (!on) return false;
+  int present = 0;
+  bool seen[4] = {false, false, false, false};
+  for (const auto& b : batches_) {
+    if (b->size() == 0) continue;
+    if (!b->population_ready() || b->type() < 0 || b->type() > 3 || seen[b->type()]) return false;
+    seen[b->type()] = true;
+    ++present;
+  }
+  return present >= 2;
+}
+
+void TargetManager::enqueuePopulationTick(hipStream_t st, long s, double dt, const Batch::SeqSpec* specs, bool query, const double* origin,
+                                          double radius, bool reverse, bool ab) {
+  StepParams parts[4];
+  for (auto& q : parts) { q = StepParams{}; q.n = 0; q.idx = nullptr; }
+  Batch* swap[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool ab_all = ab;
+  for (int pass = 0; pass < 2; ++pass) {   // (a batch without room for its second record buffer puts the whole tick in place)
+    for (size_t b = 0; b < batches_.size(); ++b) {
+      if (batches_[b]->size() == 0) continue;
+      const int t = batches_[b]->type();
+      parts[t] = batches_[b]->tick_params(s, dt, specs[b], query, origin, radius, ab_all);
+      if (ab_all && !parts[t].rec_out) { ab_all = false; break; }
+      swap[t] = batches_[b].get();
+    }
+    if (ab_all == ab || pass == 1) break;
+  }
+  if (!ab_all) for (auto& q : parts) q.rec_out = nullptr;
+  launch_population_step(dtype_, parts, query, ab_all, reverse, st);
+  if (ab_all) for (auto* b : swap) if (b) b->swap_records();
+}
+
 void TargetManager::stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpec* specs, long n_specs, bool query,
                                     const double* origin, double radius, int use_graph) {
   lock_guard<mutex> lg(target_lock_);
@@ -1122,11 +1161,16 @@ void TargetManager::stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpe
     // A -> B ticks (Batch::pingpong_min_bytes) by the size of the WHOLE population: what decides is how much is streamed
     // between two uses of a record, not which batch it belongs to
     const bool ab = Batch::pingpong_min_bytes() >= 0 && state >= Batch::pingpong_min_bytes();
+    const bool pop = populationTick();
     for (long s = 0; s < n_ticks; ++s) {
       const bool rev = zz && seq_flip_;
-      for (size_t k = 0; k < nb; ++k) {
-        const size_t b = rev ? nb - 1 - k : k;
-        batches_[b]->enqueue_tick(stream_, s, dt, specs[b], query, org, radius, rev, ab);
+      if (pop) {
+        enqueuePopulationTick(stream_, s, dt, specs, query, org, radius, rev, ab && !query);
+      } else {
+        for (size_t k = 0; k < nb; ++k) {
+          const size_t b = rev ? nb - 1 - k : k;
+          batches_[b]->enqueue_tick(stream_, s, dt, specs[b], query, org, radius, rev, ab);
+        }
       }
       seq_flip_ = !seq_flip_;
     }
@@ -1180,6 +1224,14 @@ void TargetManager::stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpe
       TE_HIP_CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
       try {
         Nodes leaves, none;
+        if (populationTick()) {
+          // one launch per tick for the whole population: a single chain, nothing left to the placement of branches on
+          // hardware queues (kf_step_sep.hpp, kf_step_population_kernel)
+          long state = 0;
+          for (size_t b = 0; b < nb; ++b) state += batches_[b]->state_bytes();
+          const bool zz = state >= Batch::zigzag_min_bytes();
+          for (long s = 0; s < n_ticks; ++s) enqueuePopulationTick(cap, s, dt, specs, query, org, radius, zz && (s & 1) != 0, false);
+        } else
         for (size_t b = 0; b < nb; ++b) {
           if (batches_[b]->size() == 0) continue;
           set_deps(none);                                  // a new chain: no predecessor
@@ -1192,7 +1244,7 @@ void TargetManager::stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpe
           leaves.insert(leaves.end(), tail.begin(), tail.end());
         }
         TE_HIP_CHECK(hipGetLastError());
-        set_deps(leaves);
+        if (!leaves.empty()) set_deps(leaves);
       } catch (...) {
         hipGraph_t broken = nullptr;
         (void)hipStreamEndCapture(cap, &broken);   // leave capture mode before reporting

@@ -214,6 +214,9 @@ class TargetManager {
   };
   std::vector<SeqGraph> seq_graphs_;
   std::vector<hipStream_t> branch_streams_;   // [0]: the capture stream
+  bool populationTick() const;   // the tick of all batches as one launch (kf_population.hpp)
+  void enqueuePopulationTick(hipStream_t st, long s, double dt, const Batch::SeqSpec* specs, bool query, const double* origin, double radius,
+                             bool reverse, bool ab);
   std::vector<hipEvent_t> branch_events_;
   void dropSeqGraphs();
   // device-side id resolution for the array-of-ids calls (id_resolve.hpp): the table and the staging of one call

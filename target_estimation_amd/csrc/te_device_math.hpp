@@ -75,7 +75,9 @@ template <typename T> __device__ __forceinline__ void quat_normalize(T* q) {
 }
 
 // geometry.hpp:154-176 quatToRpy (gimbal branches at |sin pitch| > 0.9999)
-template <typename T> __device__ __forceinline__ void quat_to_rpy(const T* q, T* rpy) {
+// SERIAL: the three inverse trigonometric functions one after the other (scheduling barriers between them) instead of interleaved:
+// same values, a third of the temporaries -- for kernels whose capacity is their register count (the resident fp64 kernels).
+template <typename T, bool SERIAL = false> __device__ __forceinline__ void quat_to_rpy(const T* q, T* rpy) {
   const T x = q[0], y = q[1], z = q[2], w = q[3];
   const T sp = -2 * (x * z - w * y);
   if (sp > (T)0.9999) {
@@ -84,7 +86,9 @@ template <typename T> __device__ __forceinline__ void quat_to_rpy(const T* q, T*
     rpy[0] = 0; rpy[1] = -pi_v<T>() / 2; rpy[2] = 2 * Mth<T>::atan2(z, w);
   } else {
     rpy[0] = Mth<T>::atan2(2 * (y * z + w * x), (w * w - x * x - y * y + z * z));
+    if constexpr (SERIAL) __builtin_amdgcn_sched_barrier(0);
     rpy[1] = Mth<T>::asin(sp);
+    if constexpr (SERIAL) __builtin_amdgcn_sched_barrier(0);
     rpy[2] = Mth<T>::atan2(2 * (x * y + w * z), (w * w + x * x - y * y - z * z));
   }
 }

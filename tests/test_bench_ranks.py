@@ -196,12 +196,14 @@ def test_single_gpu_line_parses_and_carries_roofline_and_cpu_baseline(tmp_path):
 
 @pytest.mark.gpu
 def test_extras_that_overrun_their_deadline_do_not_cost_the_line(tmp_path):
-    """Everything after the line is optional: with a deadline the extras cannot meet, the process still exits 0 with the
-    line as the last stdout line, says so on stderr, and the side file marks the extras as incomplete."""
+    """Everything after the line is optional: with a deadline the extras cannot meet, the line is still the last stdout line;
+    the process says which extra it was in, marks the side file, and leaves with status 4 -- a stalled extra (a hang, a resident
+    session that never ends) must not be recorded as a clean run."""
     side = str(tmp_path / "side.json")
     p, line = _run(["--workload", "cfg2", "--steps", "8", "--warmup", "2", "--reps", "2", "--no-cpu", "--extra", "ar4m64,av4m64,uv10m,ua10m", "--extra-steps", "64",
                     "--post-deadline", "0.05", "--side-file", side], timeout=600)
-    assert p.returncode == 0, p.stderr[-3000:]
+    assert p.returncode == 4, p.stderr[-3000:]
     assert line is not None and line["value"] > 0 and json.loads(p.stdout.strip().splitlines()[-1]) == line
-    assert "did not finish within" in p.stderr
-    assert json.load(open(side)).get("extras_incomplete") is True
+    assert "did not finish within" in p.stderr and "running: ar4m64" in p.stderr
+    sidej = json.load(open(side))
+    assert sidej.get("extras_incomplete") is True and sidej.get("stalled_in") == "ar4m64"

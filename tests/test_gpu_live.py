@@ -5,6 +5,8 @@ replaces: the caller's per-tick loop over targets, src/target_manager.cpp:190-22
 
 Every test drives the manager on its own NON-blocking stream and refills the ring on another one: work queued behind the
 resident kernel on its stream (or on the legacy default stream) would wait for the session to end."""
+import os
+
 import numpy as np
 import pytest
 
@@ -190,13 +192,13 @@ def test_two_models_resident_together_on_the_default_stream(models, dtype):
     from target_estimation_amd.streams import make_stream
     parts = bench.MIXED["cfg4"][1]
     if dtype == "f64":
-        # the fp64 angular kernels hold a wavefront's state in 262 / 282 registers: one wavefront per SIMD, and 2 x 977 of them
-        # (+ relays) are more than the device holds at once -- the manager must say so instead of starting a session that
-        # cannot be fully resident
-        big, bmeas, _ = None, None, None
+        # Round 3: the fp64 angular kernels held a wavefront's state in 262 / 282 registers, one wavefront per SIMD, and the
+        # configs[3] share did not fit.  Now (part of the record parked in LDS, no loop-invariant constants in vector registers:
+        # 125-167 registers, three wavefronts per SIMD) it does and runs below at the full share.  What does NOT fit any more is
+        # 200 000 + 200 000: the manager must say so instead of starting a session that cannot be fully resident.
         mgr = te.TargetManager(dtype=dtype)
         rings, base = [], 0
-        for k, (name, n) in enumerate(parts):
+        for k, (name, n) in enumerate([(name, 200_000) for name, _ in parts]):
             m = models[name]
             ids = np.arange(n, dtype=np.uint32) + base
             base += n
@@ -206,7 +208,6 @@ def test_two_models_resident_together_on_the_default_stream(models, dtype):
             mgr.live_start_all(0.004, rings)
         assert not any(b._lib.target_batch_live_done(b._h) for b in mgr.batches())
         mgr.close()
-        parts = [(name, 20_000) for name, _ in parts]
     ticks, dt = 12, 0.004
 
     def build():
@@ -468,10 +469,12 @@ def test_sessions_with_one_hardware_queue_per_priority():
 
 
 def test_a_second_session_that_does_not_fit_next_to_the_first_is_refused_cleanly(models):
-    """Two managers, each within ITS capacity, together more than the device holds: the second session's grid is only partly
-    resident, its last workgroup (the relay) never starts.  live_start must say so after its start timeout, get the workers
-    that did start out of the way (the stop word goes into their mirror words from the host), leave the second manager usable
-    at once -- and the first session must go on serving ticks."""
+    """Two managers, each within ITS capacity, together more than the device holds.  The library counts the resident sessions
+    of the process, so the second start is refused at once.  With that count switched off (TE_LIVE_IGNORE_OTHERS=1: what a
+    session of ANOTHER process looks like) the second grid is only partly resident and its last workgroup (the relay) never
+    starts: live_start must say so after its start timeout, get the workers that did start out of the way (the stop word goes
+    into their mirror words from the host), leave the second manager usable at once -- and the first session must go on
+    serving ticks.  Calls that free device memory next to the resident session return at once (the frees wait on a list)."""
     import time
     name, dtype, dt = "uniform_acceleration", "f32", 0.004
     probe = te.TargetManager(model_path(name), dtype=dtype)
@@ -486,17 +489,32 @@ def test_a_second_session_that_does_not_fit_next_to_the_first_is_refused_cleanly
     a.live_post(2)
     assert a.live_wait(2, 5.0)
     t0 = time.perf_counter()
-    with pytest.raises(RuntimeError, match="did not start within"):
+    with pytest.raises(RuntimeError, match="do not fit the device together"):
         b.live_start(dt, st_b["meas"], max_ticks=8, idle_limit_s=20.0)
-    assert time.perf_counter() - t0 < 6.0
+    assert time.perf_counter() - t0 < 0.5
+    os.environ["TE_LIVE_IGNORE_OTHERS"] = "1"
+    try:
+        t0 = time.perf_counter()
+        with pytest.raises(RuntimeError, match="did not start within"):
+            b.live_start(dt, st_b["meas"], max_ticks=8, idle_limit_s=20.0)
+        assert time.perf_counter() - t0 < 6.0
+    finally:
+        del os.environ["TE_LIVE_IGNORE_OTHERS"]
     t0 = time.perf_counter()
     ok, pose = mgr_b.getTargetPose(int(ids_b[5]))               # the refused manager: usable at once, records untouched
     assert ok and np.allclose(pose[:3], p0_b[5, :3])
     b.step(dt, st_b["meas"][0])
     mgr_b.synchronize()
-    assert time.perf_counter() - t0 < 2.0
-    # (calls that FREE device memory -- get_state_batch's scratch buffers, a batch that grows -- wait for every kernel of the
-    # process, a resident one included: hipFree synchronises the device.  Not used next to somebody else's session.)
+    # calls that FREE device memory (hipFree synchronises the device: next to the resident session it would block until the
+    # session's idle limit, 20 s here): the measured-pose rows of a batch, and a batch that grows
+    mgr_b.set_keep_measurement(True)
+    mgr_b.set_keep_measurement(False)
+    grow = np.arange(nb, nb + 70_000, dtype=np.uint32) + 10_000_000
+    pg = np.zeros((len(grow), 7)); pg[:, 6] = 1
+    assert mgr_b.init_batch(grow, dt, 0.0, pg) == len(grow)
+    assert mgr_b.erase_batch(grow) == len(grow)
+    mgr_b.synchronize()
+    assert time.perf_counter() - t0 < 3.0
     a.live_post(6)                                              # the first session never noticed
     assert a.live_wait(8, 5.0) and a.live_stop() == 8
     ref = te.TargetManager(model_path(name), dtype=dtype)
