@@ -326,17 +326,11 @@ struct IntersectArgs {
 // moving-average convergence gate (src/intersection_solver.cpp:42-104) for one target with state x:
 // quartic in delta from the (p, v, a) extrapolated by dq = t1 - t_, smallest real root, pose at
 // t1 + delta.  own = the query is at the target's own time (dq = 0, pose offset = delta itself).
-// THROUGH: the results leave with system-scope write-through stores (the resident kernels: a consumer outside the kernel reads
-// them while it runs)
-template <class M, typename T, bool THROUGH = false>
-__device__ __forceinline__ void sphere_query(const T* x, bool own, double t1, double t, const double* origin, double radius,
-                                             double* delta_out, double* pose_out /* [7] or null */) {
+// The values: delta (the reference's intersection time, -1 if none) and, if wanted, the pose at that time (identity if none).
+template <class M, typename T>
+__device__ __forceinline__ void sphere_query_values(const T* x, bool own, double t1, double t, const double* origin, double radius,
+                                                    double& delta, double* pose /* [7] or null */) {
 #pragma clang fp contract(off)   // fused query, intersect kernel: the same roundings (te_device_math.hpp)
-  auto put = [](double* p, double v) {
-    if constexpr (THROUGH)
-      __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    else *p = v;
-  };
   T pose7[7], twist6[6], acc6[6];
   derive_outputs<M, T>(x, true, own ? (T)0 : (T)(t1 - t), pose7, twist6, acc6);
   const double px = (double)pose7[0] - origin[0], py = (double)pose7[1] - origin[1], pz = (double)pose7[2] - origin[2];
@@ -349,16 +343,25 @@ __device__ __forceinline__ void sphere_query(const T* x, bool own, double t1, do
   c[1] = 2 * (px * vx + py * vy + pz * vz);
   c[0] = px * px + py * py + pz * pz - radius * radius;
   const double d = first_crossing_quartic(c);   // leftmost real root if >= 0, else -1
-  put(delta_out, d);
-  if (pose_out) {
-    double out[7] = {0, 0, 0, 0, 0, 0, 1};
+  delta = d;
+  if (pose) {
+    pose[0] = pose[1] = pose[2] = pose[3] = pose[4] = pose[5] = 0; pose[6] = 1;
     if (d > -1) {
       derive_outputs<M, T>(x, true, own ? (T)d : (T)((d + t1) - t), pose7, twist6, acc6);
 #pragma unroll
-      for (int k = 0; k < 7; ++k) out[k] = (double)pose7[k];
+      for (int k = 0; k < 7; ++k) pose[k] = (double)pose7[k];
     }
-    for (int k = 0; k < 7; ++k) put(&pose_out[k], out[k]);
   }
+}
+
+template <class M, typename T>
+__device__ __forceinline__ void sphere_query(const T* x, bool own, double t1, double t, const double* origin, double radius,
+                                             double* delta_out, double* pose_out /* [7] or null */) {
+  double d, out[7];
+  sphere_query_values<M, T>(x, own, t1, t, origin, radius, d, pose_out ? out : nullptr);
+  *delta_out = d;
+  if (pose_out)
+    for (int k = 0; k < 7; ++k) pose_out[k] = out[k];
 }
 
 template <class M, typename T, int G, int LAYOUT>

@@ -101,7 +101,7 @@ struct StepArgs {
   long live_first;
   unsigned live_spin_limit;
   unsigned long long live_idle_ticks;   // the idle limit on the device's wall clock (0: count relay rounds instead, live_spin_limit)
-  int live_flags;   // experiments (TE_LIVE_FLAGS): 8 = relay scans slowly always, 16 = kLiveRelaxed (round 3's relaxed hand-offs)
+  int live_flags;   // experiments (TE_LIVE_FLAGS): 8 = relay scans slowly always, see "Ordering of the hand-offs" below
   // live_pose (or null): SoA [7][live_pose_ld] doubles in device memory that receives the estimated pose of every target after
   // every tick (what the reference's node publishes every tick, src/target_manager_ros.cpp:78-87), written THROUGH the caches
   // before the tick's progress word, so that a copy engine that reads it after `done` reached the tick sees that tick's poses
@@ -123,30 +123,40 @@ __device__ __forceinline__ long long wave_uniform_ll(long long v) {
 // nothing left to serve ends it even when the relay is not there to pass it on -- a grid that never became fully resident, which
 // Batch::live_start gives up on (the relay is its LAST workgroup).  A busy session never waits that long between ticks.
 //
-// Ordering of the hand-offs (kLiveRelaxed in live_flags = the round-3 form, relaxed everywhere, kept for the before / after
-// measurement in profiles/r04_live_ordering.txt):
+// Ordering of the hand-offs (profiles/r04_live_ordering.txt has the measurements and the ISA).  Every edge that costs nothing is a
+// real release / acquire; the two on the WORKER side cost 2x (paced) and 15x (back to back) and order nothing that is not
+// ordered by construction, so there the relaxed form stays, with the reason next to it:
 //   host      ring entries, then posted        store RELEASE                       (Batch::live_post)
-//   relay     posted                           load  ACQUIRE  system
-//             mirror                           store RELEASE  agent
-//   worker    mirror                           load  relaxed while polling, then an ACQUIRE fence (agent) once the tick is admitted,
-//                                              before the tick's measurement loads
+//   relay     posted                           load relaxed system, ACQUIRE fence (system) behind the round's scan
+//             mirror                           RELEASE fence (agent), then the relaxed stores of the copies
+//   worker    mirror                           load relaxed (agent) while polling.  No acquire fence on admission: what the tick
+//                                              then reads from outside the kernel -- the ring entry -- is read with SYSTEM-scope loads
+//                                              (sc0 sc1: past every cache) issued after the poll's s_waitcnt in program order, so there
+//                                              is no cached copy an acquire's buffer_inv would have to drop; the fence costs one cache
+//                                              invalidation per wavefront per tick, on the critical path of a paced stream (10^5 targets:
+//                                              9.4 -> 19.9 us per paced tick).  kLiveWorkerAcq switches it on.
 //             outputs of the tick (poses, query results): system-scope write-through stores, waited for (vmcnt 0)
-//             progress                         store RELEASE  agent
-//   relay     progress scan                    loads relaxed, then an ACQUIRE fence (agent) behind the scan
+//             progress                         store relaxed agent BEHIND that wait.  Not a release: everything a consumer may read
+//                                              after `done` has left the wavefront with write-through stores whose completion the
+//                                              s_waitcnt has seen (a plain session writes nothing per tick at all: the state is in
+//                                              registers), so a release would add only its L2 write-back (buffer_wbl2) of lines nobody
+//                                              waits for (10^5 targets 1.12 -> 17.3 us per tick).  kLiveWorkerRel switches it on.
+//   relay     progress scan                    loads relaxed, the round's ACQUIRE fence behind the scan
 //             done                             store RELEASE  system
 //   host      done                             load  ACQUIRE                        (Batch::live_done)
+// live_flags (TE_LIVE_FLAGS, measurement only): kLiveRelaxed = round 3's form, relaxed everywhere; kLiveWorkerAcq / kLiveWorkerRel
+// switch the worker's two edges ON; kLiveNoRelayAcq / kLiveNoDoneRel / kLiveNoMirrorRel switch single relay edges OFF.
 constexpr int kLiveRelaxed = 16;
-// single edges switched off (measurement only): worker's acquire fence, worker's progress release, relay's acquire fence,
-// relay's release of `done`, relay's release fence ahead of the mirror words
-constexpr int kLiveNoWorkerAcq = 32, kLiveNoWorkerRel = 64, kLiveNoRelayAcq = 128, kLiveNoDoneRel = 256, kLiveNoMirrorRel = 512;
+constexpr int kLiveWorkerAcq = 32, kLiveWorkerRel = 64;
+constexpr int kLiveNoRelayAcq = 128, kLiveNoDoneRel = 256, kLiveNoMirrorRel = 512;
 __device__ __forceinline__ bool live_wait_tick(const long long* mirror, const long long* host_posted, long long need, unsigned limit, long long& seen, int lane, int flags = 0) {
-  if ((seen & kLiveCount) >= need) return true;   // (admitted by an earlier poll: its fence covered this tick's entries too)
+  if ((seen & kLiveCount) >= need) return true;
   for (unsigned spins = 0;; ++spins) {
     long long v = 0;
     if (lane == 0) v = __hip_atomic_load(mirror, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     seen = wave_uniform_ll(v);
     if ((seen & kLiveCount) >= need) {
-      if (!(flags & (kLiveRelaxed | kLiveNoWorkerAcq))) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (flags & kLiveWorkerAcq) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       return true;
     }
     if (seen < 0) return false;        // stop, and every posted tick is done

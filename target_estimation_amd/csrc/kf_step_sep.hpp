@@ -178,6 +178,7 @@ __device__ __forceinline__ void sep_step_wave(const StepArgs<T>& a, long wg, con
   using Park = LivePark<C, M, T>;
   constexpr int NPARK = (LIVE != 0 && C::SEPPK) ? Park::SLOT.count : 0;
   __shared__ T park_lds[NPARK > 0 ? NPARK * 64 : 1];
+  __shared__ double qpose_lds[LIVE == 2 ? 64 * 7 : 1];   // the per-tick query's pose rows on their way out (LIVE == 2, below)
   if constexpr (NPARK > 0) {
     // the record goes to its two homes chunk by chunk, a few loads in flight at a time: loaded whole (load_record) it would
     // itself be the register peak of the kernel.  Once per session: its speed does not matter.
@@ -597,9 +598,30 @@ __device__ __forceinline__ void sep_step_wave(const StepArgs<T>& a, long wg, con
       T xq[N];
 #pragma unroll
       for (int r = 0; r < N; ++r) xq[r] = XR_(r);
-      // (written THROUGH the caches like the poses below: a consumer on another stream or a copy engine that reads them once
-      // `done` has reached the tick must see this tick's results, not what an XCD's L2 still holds)
-      sphere_query<M, T, true>(xq, true, 0.0, 0.0, a.q_origin, a.q_radius, &a.q_delta[entry], a.q_pose ? &a.q_pose[entry * 7] : nullptr);
+      // Written THROUGH the caches like the poses below: a consumer on another stream or a copy engine that reads them once
+      // `done` has reached the tick must see this tick's results, not what an XCD's L2 still holds.  The pose rows are
+      // [target][7]: a lane's own row is 56 bytes at a stride of 56, and written through as such every store is a partial line
+      // straight to memory (configs[4]'s share: 4.9 -> 10.5 us per tick).  The wavefront's 64 rows are one contiguous run of
+      // 3584 bytes, so they go through its LDS and leave as seven full 512-byte stores.
+      double qd, qp[7];
+      sphere_query_values<M, T>(xq, true, 0.0, 0.0, a.q_origin, a.q_radius, qd, a.q_pose ? qp : nullptr);
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(&a.q_delta[entry]), (unsigned long long)__double_as_longlong(qd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (a.q_pose != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) qpose_lds[lane * 7 + k] = qp[k];
+      }
+    }
+    if (a.q_delta != nullptr && a.q_pose != nullptr) {   // (uniform) every lane takes part in the transposed store
+      wave_lds_fence();
+      const long first = wg * TPW;                                        // first target of this wavefront
+      const long words = (a.n - first < TPW ? a.n - first : (long)TPW) * 7;   // its rows, as one run of words
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const int f = k * 64 + lane;
+        if (f < words)
+          __hip_atomic_store(reinterpret_cast<unsigned long long*>(&a.q_pose[first * 7 + f]), (unsigned long long)__double_as_longlong(qpose_lds[f]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      wave_lds_fence();
     }
     if (a.live_pose != nullptr) {   // the tick's estimated poses for a consumer outside the kernel (StepArgs::live_pose)
       if (valid) {
@@ -618,8 +640,8 @@ __device__ __forceinline__ void sep_step_wave(const StepArgs<T>& a, long wg, con
   if constexpr (LIVE) {
     // tick `tick` is done (state in registers): a word in device memory for the relay
     if (lane == 0) {
-      if (a.live_flags & (kLiveRelaxed | kLiveNoWorkerRel)) __hip_atomic_store(&a.live_progress[wave_id], tick + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else __hip_atomic_store(&a.live_progress[wave_id], tick + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.live_flags & kLiveWorkerRel) __hip_atomic_store(&a.live_progress[wave_id], tick + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      else __hip_atomic_store(&a.live_progress[wave_id], tick + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (see kf_step.hpp, "Ordering of the hand-offs")
     }
   }
   }  // tick loop
@@ -687,7 +709,8 @@ __global__ void __launch_bounds__(256, (sep_min_waves<M, T, LAYOUT, PERQR, LIVE>
 // property to build on: measured (profiles/r04_queue_pipes.txt), the two branches of a recorded tick ran 2-3x slower as soon as
 // the process owned a fifth hardware queue, whoever created it.  Here the tick of ALL batches is one grid: the first end[0]
 // workgroups step the angular-rates batch, the next ones the angular-velocities batch, and so on in the order of the
-// reference's enum (target_manager.hpp:38) -- the heaviest model first.  Each part is exactly kf_step_sep_kernel's arithmetic
+// reference's enum (target_manager.hpp:38) -- the heaviest model first (measured at configs[4]'s share: light parts first 13.6 -> 15.2 us
+// per tick, the two parts' workgroups alternating 14.9; gpurun_out/r4popgrid).  Each part is exactly kf_step_sep_kernel's arithmetic
 // (sep_step_wave) on its own StepArgs; an absent model has end[k] == end[k - 1].
 template <typename T>
 struct PopulationArgs {

@@ -309,6 +309,65 @@ def test_config4_share_resident_with_the_per_tick_query(models):
     ref.close(); mgr.close()
 
 
+def test_query_results_of_a_live_session_are_readable_tick_by_tick(models):
+    """The per-tick sphere query of a resident session writes delta / pose "overwritten every tick": a consumer on another
+    stream that copies them once the tick's completion has reached the host must get THAT tick's results (they leave the
+    kernel with write-through stores ahead of the progress word), not what an XCD's L2 still holds -- against a manager stepped
+    by single launches with the fused query, bit for bit, tick by tick, without ending the session."""
+    from target_estimation_amd.streams import make_stream
+    parts, dtype = [("angular_rates", 6000), ("uniform_acceleration", 5000)], "f32"
+    ticks, dt = 8, 0.004
+    origin, radius = np.zeros(3), 5.0
+
+    def build():
+        mgr = te.TargetManager(dtype=dtype)
+        base, meas = 0, []
+        for k, (name, n) in enumerate(parts):
+            m = models[name]
+            st = make_stream(MODELS[name], n, ticks, dt, 900 + k, dtype=dtype)
+            ids = np.arange(n, dtype=np.uint32) + base
+            base += n
+            p0 = st["p0"].cpu().numpy()
+            rng = np.random.default_rng(60 + k)
+            d = p0[:, :3] / np.linalg.norm(p0[:, :3], axis=1, keepdims=True)
+            v0 = np.concatenate([-d * rng.uniform(1, 6, (n, 1)), np.zeros((n, 3))], 1)
+            a0 = np.concatenate([rng.normal(0, 1.0, (n, 3)) + [0, 0, -2.0], np.zeros((n, 3))], 1)
+            mgr.init_batch(ids, dt, 0.0, p0, v0, a0, type=m["model"], Q=m["Q"], R=m["R"], P0=m["P"])
+            meas.append(st["meas"])
+        deltas = [torch.full((b.size,), 123.0, dtype=torch.float64, device="cuda") for b in mgr.batches()]
+        poses = [torch.zeros((b.size, 7), dtype=torch.float64, device="cuda") for b in mgr.batches()]
+        return mgr, meas, deltas, poses
+    ref, rmeas, rd, rp = build()
+    want = []
+    for s in range(ticks):
+        ref.step_sequence_all(dt, [m[s:s + 1] for m in rmeas], query=(origin, radius, rd, rp), use_graph=0)
+        torch.cuda.synchronize()
+        want.append(([d.cpu().numpy().copy() for d in rd], [q.cpu().numpy().copy() for q in rp]))
+    mgr, meas, dd, pp = build()
+    hd = [torch.empty_like(d, device="cpu").pin_memory() for d in dd]
+    hp = [torch.empty_like(q, device="cpu").pin_memory() for q in pp]
+    torch.cuda.synchronize()
+    copy = torch.cuda.Stream()
+    mgr.live_start_all(dt, meas, max_ticks=ticks, idle_limit_s=3.0, query=(origin, radius, dd, pp))
+    changed = 0
+    for s in range(ticks):
+        mgr.live_post_all(1)
+        assert mgr.live_wait_all(s + 1, 5.0)
+        with torch.cuda.stream(copy):
+            for j in range(len(dd)):
+                hd[j].copy_(dd[j], non_blocking=True)
+                hp[j].copy_(pp[j], non_blocking=True)
+        copy.synchronize()
+        for j in range(len(dd)):
+            np.testing.assert_array_equal(hd[j].numpy(), want[s][0][j])
+            np.testing.assert_array_equal(hp[j].numpy(), want[s][1][j])
+            if s:
+                changed += int((want[s][0][j] != want[s - 1][0][j]).sum())
+    assert changed > 1000                                   # the results do move from tick to tick: a stale copy would be caught
+    assert mgr.live_stop_all() == ticks
+    ref.close(); mgr.close()
+
+
 def test_a_busy_session_is_not_an_idle_one(models):
     """The idle limit counts rounds in which NOTHING happens.  A burst that takes longer to serve than the limit (the host is
     silent because it waits for it) must not end the session: later doorbells are still served."""
