@@ -546,6 +546,31 @@ def run_mixed(te, torch, name, steps, warmup, dist=None, rank=0, world=1, stream
     kernels = [kernel_name(b, m) + ("+query" if intersect else "") for b, m in zip(batches, models)]
     extra_alg = sum(8 * 8 * b.size for b in batches) if intersect else 0   # the query writes delta + pose7 (doubles)
     res = summarize(name, desc, models, dtype, batches, kernels, n_all, world, steps, wall, dev, launch_mode, extra_alg)
+    if launch_mode in ("graph", "sequence") and mgr.population_tick():
+        # ONE launch steps every batch of the manager (csrc/kf_step_sep.hpp kf_step_population_kernel): the launch's duration is
+        # the tick's device time over the timed region itself (HIP events on the launch stream), its algorithmic bytes the sum
+        # over the models of targets x bytes per target -- no attribution pass, nothing to split
+        kname = "kf_step_population_kernel<%s>" % ("double" if dtype == "f64" else "float") + ("+query" if intersect else "")
+        per_unit = res["algorithmic_bytes_per_step"] / n_all
+        ms = res["device_ms_per_step"]
+        res["kernel"] = kname
+        res["launch_mode"] = launch_mode + ": one launch per tick for the whole population"
+        res["kernels"] = [dict(kernel=kname, model="+".join(models), units_per_launch=n_all, algorithmic_bytes_per_unit=per_unit,
+                               avg_launch_ms=ms, achieved_gbs=per_unit * n_all / (ms * 1e-3) / 1e9,
+                               frac=per_unit * n_all / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               parts=[dict(model=m, units=b.size, algorithmic_bytes_per_unit=b.algorithmic_bytes + (64 if intersect else 0))
+                                      for b, m in zip(batches, models)],
+                               note="one launch = one tick of every batch; algorithmic_bytes_per_unit is the mean over the population "
+                                    "(sum over parts of units x bytes / units_per_launch)" + ("; the query's delta + pose7 outputs (64 B per target) included" if intersect else ""))]
+        for b in batches:
+            p, _, _ = b.get_est(twist=False, acc=False)
+            assert torch.isfinite(p).all()
+        if intersect:
+            res["intersections_last_tick"] = sum(int((o[0] > -1).sum()) for o in outs)
+        res["measurement_ring_ticks"] = ticks
+        res["measurement_ring_bytes"] = int(sum(m.numel() * m.element_size() for m in meas))
+        mgr.close()
+        return res
     # Attribution pass (same kernels, same data, same stream, same launch order as the timed region, right after it): one
     # HIP event between consecutive launches -> average duration of every kernel IN ITS CONTEXT (alone, a 500 000-target
     # batch would sit in the Infinity Cache and look faster than it is inside the tick).
@@ -1119,7 +1144,8 @@ def main():
                                     "between consecutive launches in a pass with the timed region's launch order, right after it",
                      "bytes_rule": "bytes the kernel reads + writes per target: 2n + 2|P stored| + measurement words read (3 linear, 7 angular) "
                                    "(+6 unwrap words, angular); SURVEY 8d's full-P figure for this model is survey_full_P_bytes_per_unit",
-                     "survey_full_P_bytes_per_unit": SURVEY_WORDS[dom["model"]] * (8 if res["dtype"] == "f64" else 4),
+                     "survey_full_P_bytes_per_unit": (sum(q["units"] * SURVEY_WORDS[q["model"]] for q in dom["parts"]) / dom["units_per_launch"]
+                                                      if "parts" in dom else SURVEY_WORDS[dom["model"]]) * (8 if res["dtype"] == "f64" else 4),
                      "tick": {"achieved": res["achieved_gbs"], "frac": res["achieved_gbs"] / HBM_PEAK_GBS,
                               "algorithmic_bytes_per_step": res["algorithmic_bytes_per_step"], "device_ms_per_step": res["device_ms_per_step"],
                               "note": "all kernels of the tick over the timed region itself (events on the launch stream)"},

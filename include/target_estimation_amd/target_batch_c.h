@@ -284,9 +284,13 @@ int target_batch_live_running(target_batch_c* b);
  * batch i (target_manager_get_batch order): measurements as for target_batch_step_sequence, plus the
  * device outputs of the query (delta [size], pose [size][7] or NULL; overwritten every tick) when
  * query != 0.  The query is the own-time one (t1 = each target's current time).  Batches are
- * independent; with use_graph != 0 their launch chains are recorded as parallel branches of ONE
- * hipGraph and run concurrently (use_graph == 2: record only).  Results are identical to calling
- * target_batch_step (+ target_batch_intersect_sphere_dev with a NaN t1) per batch per tick. */
+ * independent.  When every non-empty batch is a one-class batch in the axis-separable layout with packed
+ * groups (the automatic choice for the shipped model files) and there are at least two, a tick of ALL of
+ * them is ONE launch (csrc/kf_step_sep.hpp kf_step_population_kernel; target_manager_population_tick says
+ * whether that holds): nothing then depends on which hardware queues the runtime gives to concurrent
+ * streams.  Otherwise there is a launch per batch per tick; with use_graph != 0 the batches' chains are
+ * recorded as parallel branches of ONE hipGraph (use_graph == 2: record only).  Results are identical to
+ * calling target_batch_step (+ target_batch_intersect_sphere_dev with a NaN t1) per batch per tick. */
 typedef struct target_batch_sequence_c {
   const void* meas_dev; long tick_stride; long ld;
   const unsigned char* has_meas_dev; long has_stride;
@@ -295,6 +299,9 @@ typedef struct target_batch_sequence_c {
 } target_batch_sequence_c;
 int target_manager_step_sequence_all(target_manager_c* m, long n_ticks, double dt, const target_batch_sequence_c* per_batch,
                                      long n_batches, int query, const double* origin, double radius, int use_graph);
+/* 1 if target_manager_step_sequence_all currently steps all batches with one launch per tick, 0 if with a launch per
+ * batch, -1 on error (semantics served: every target of every model each tick, src/target_manager.cpp:190-225) */
+int target_manager_population_tick(target_manager_c* m);
 /* Resident ("live") mode (target_batch_live_* above) for EVERY batch of a manager at once (BASELINE.json configs[3] / configs[4]: two motion models per GPU, whose per-GPU
  * share is launch-bound): one resident kernel per batch, each on a stream of its own so that they are on the device together;
  * per_batch[i] describes batch i's ring as for target_manager_step_sequence_all (ring_ticks > 0); with query != 0 the own-time

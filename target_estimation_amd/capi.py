@@ -123,6 +123,7 @@ SIGNATURES = {
     "target_batch_step_host": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_long, C.c_void_p]),
     "target_batch_step_sequence": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_int]),
     "target_batch_step_sequence_ring": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_int]),
+    "target_manager_population_tick": (C.c_int, [C.c_void_p]),
     "target_manager_step_sequence_all": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_long, C.c_int, c_double_p, C.c_double, C.c_int]),
     "target_batch_step_fused": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long]),
     "target_batch_live_start": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_long,

@@ -146,6 +146,7 @@ class TargetManager {
   // independent, so with use_graph != 0 each batch's chain of launches is its own branch of one hipGraph
   // and the branches run concurrently; the query runs inside the step kernel (QUERY variants).
   // use_graph == 2 records without launching.  use_graph == 0 issues the same launches eagerly, batch after batch per tick.
+  bool populationTickNow() { std::lock_guard<std::mutex> lg(target_lock_); return populationTick(); }
   void stepSequenceAll(long n_ticks, double dt, const Batch::SeqSpec* specs, long n_specs, bool query,
                        const double* origin, double radius, int use_graph);
 
@@ -214,7 +215,7 @@ class TargetManager {
   };
   std::vector<SeqGraph> seq_graphs_;
   std::vector<hipStream_t> branch_streams_;   // [0]: the capture stream
-  bool populationTick() const;   // the tick of all batches as one launch (kf_population.hpp)
+  bool populationTick() const;   // the tick of all batches as one launch (kf_population.hpp); caller holds target_lock_
   void enqueuePopulationTick(hipStream_t st, long s, double dt, const Batch::SeqSpec* specs, bool query, const double* origin, double radius,
                              bool reverse, bool ab);
   std::vector<hipEvent_t> branch_events_;

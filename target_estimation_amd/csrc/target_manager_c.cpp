@@ -409,6 +409,12 @@ int target_manager_step_sequence_all(target_manager_c* m, long n_ticks, double d
   });
 }
 
+int target_manager_population_tick(target_manager_c* m) {
+  int on = 0;
+  const int rc = guarded("target_manager_population_tick", [&] { on = M(m)->populationTickNow() ? 1 : 0; });
+  return rc < 0 ? -1 : on;
+}
+
 int target_batch_step_fused(target_batch_c* b, long n_ticks, double dt, const void* meas_dev, long tick_stride, long ld,
                             const unsigned char* has_meas_dev, long has_stride) {
   return guarded("target_batch_step_fused", [&] { BatchLock lk(B(b));

@@ -530,6 +530,10 @@ class TargetManager:
             self._h, ticks, float(dt), C.cast(specs, C.c_void_p), nb, 0 if query is None else 1,
             None if origin is None else _dp(origin), float(radius), int(use_graph)), "target_manager_step_sequence_all")
 
+    def population_tick(self):
+        """True if step_sequence_all steps every batch with ONE launch per tick (target_manager_population_tick)."""
+        return _check(self._lib.target_manager_population_tick(self._h), "target_manager_population_tick") == 1
+
     # ---- resident ("live") mode of every batch at once (target_batch_c.h)
     def live_start_all(self, dt, meas, has_meas=None, first_entry=0, max_ticks=1 << 30, idle_limit_s=10.0, query=None):
         """meas: one CUDA ring tensor [ring_ticks, 7, ld] per batch (batches() order).  query = (origin[3], radius, deltas, poses)

@@ -29,6 +29,9 @@ sys.path.insert(0, ROOT)
 def short_kernel(name):
     """'void te::kf_step_sep_kernel<te::ModelAR, double, 3, false, ...>(...)' -> 'kf_step_sep_kernel<ModelAR,double,3>'
     (the form bench.py's kernel_name() prints): model, type, then LAYOUT (separable) or G, LAYOUT (dense)."""
+    pm = re.search(r"kf_step_population_kernel<(double|float), (true|false), (true|false)>", name.replace("te::", ""))
+    if pm:   # the whole population of a manager in one launch: <T, QUERY, AB>
+        return "kf_step_population_kernel<%s>" % pm.group(1) + ("+query" if pm.group(2) == "true" else "")
     m = re.search(r"(kf_step(?:_sep)?_kernel)<([^>]*)>", name.replace("te::", ""))
     if not m:
         return None
