@@ -890,6 +890,42 @@ def copy_bandwidth(torch, nbytes=1 << 30, reps=10):
     return dict(copy=rate(lambda: c.copy_(a), 2.0 * nbytes), triad=rate(lambda: torch.add(a, b, out=c), 3.0 * nbytes))
 
 
+def previous_side_file():
+    """The newest committed side file of an EARLIER collection (profiles/rNN_bench_extra*.json), for the slow-down check below."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_extra*.json")):
+        m = re.match(r"r(\d\d)_bench_extra(_head)?\.json$", os.path.basename(f))
+        if m:
+            key = (int(m.group(1)), 1 if m.group(2) else 0)
+            if best is None or key > best[0]:
+                best = (key, f)
+    if best is None:
+        return None, {}
+    try:
+        d = json.load(open(best[1]))
+    except (OSError, ValueError):
+        return None, {}
+    rows = {e["name"]: e["ms_per_step"] for e in d.get("extra", []) if "ms_per_step" in e}
+    if "line" in d:
+        rows[d["line"]["config"]["name"]] = d["line"]["ms_per_step"]
+    return os.path.relpath(best[1], ROOT), rows
+
+
+def slowdown_check(rows_now, factor=1.25):
+    """Workloads that take more than `factor` x their time in the committed previous side file: one stderr line each, and the
+    list for the side file.  (Round 3 shipped a 2-3x slow-down of three rows that no record said anything about.)"""
+    src, before = previous_side_file()
+    slow = []
+    for name, ms in rows_now.items():
+        if name in before and before[name] > 0 and ms > factor * before[name]:
+            slow.append(dict(name=name, ms_per_step=ms, previous_ms_per_step=before[name], ratio=ms / before[name], previous_record=src))
+            print("bench.py: WARNING: %s takes %.4f ms per step, %.2f x its %.4f ms in %s" % (name, ms, ms / before[name], before[name], src),
+                  file=sys.stderr, flush=True)
+    return slow
+
+
 def load_traffic():
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json, tools/pmc_traffic.py):
     {workload: {kernel: {hbm_read_bytes, hbm_write_bytes}}}.  PMC counters cannot be read from inside this process."""
@@ -1297,6 +1333,9 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     post_timer.cancel()
+    if rank == 0 and world == 1:
+        side["slower_than_previous_record"] = slowdown_check(
+            dict({e["name"]: e["ms_per_step"] for e in extras if "ms_per_step" in e}, **{out["config"]["name"]: out["ms_per_step"]}))
     if rank == 0:
         write_side(args, dict(side, line=out))
         print(json.dumps(dict(side, line=out)), file=sys.stderr)

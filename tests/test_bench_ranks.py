@@ -100,6 +100,19 @@ def test_strong_scaling_rows_come_first_for_n_gt_1():
         assert base in bench.WORKLOADS or base in bench.MIXED
 
 
+def test_a_workload_much_slower_than_the_committed_record_is_reported(capsys):
+    """bench.py compares every workload of a run with the newest committed side file and says so on stderr (and in the side
+    file) when one takes more than 1.25 x its recorded time."""
+    sys.path.insert(0, ROOT)
+    import bench
+    src, before = bench.previous_side_file()
+    assert src is not None and src.startswith("profiles/") and "cfg4" in before and "cfg4_1gpu" in before
+    slow = bench.slowdown_check({"cfg4": 2.0 * before["cfg4"], "cfg2": 1.1 * before["cfg2"], "not_in_the_record": 1.0})
+    assert [e["name"] for e in slow] == ["cfg4"] and abs(slow[0]["ratio"] - 2.0) < 1e-9 and slow[0]["previous_record"] == src
+    err = capsys.readouterr().err
+    assert "WARNING: cfg4 takes" in err and "cfg2" not in err
+
+
 def _fake_result():
     """A result record of the shape run_mixed() returns, with the longest strings bench.py can produce."""
     sys.path.insert(0, ROOT)

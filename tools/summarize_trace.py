@@ -26,7 +26,8 @@ def main():
             groups[(short(r["Kernel_Name"]), g)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     print("# rocprofv3 --kernel-trace --stats summary; template arguments of kf_step_sep_kernel: <model, precision, layout (2 = separable,")
     print("# 3 = separable + packed), INDEXED, FUSED, QUERY, PERQR, LIVE (1 = resident, 2 = resident with per-tick query / pose output), AB>, of kf_step_kernel:")
-    print("# <model, precision, lanes per target, layout (0 = full, 1 = packed), INDEXED, FUSED, QUERY, PERQR, AB>")
+    print("# <model, precision, lanes per target, layout (0 = full, 1 = packed), INDEXED, FUSED, QUERY, PERQR, AB>; kf_step_population_kernel<precision, QUERY, AB>:")
+    print("# ONE launch for every batch of a manager (grid = the sum over the models of their targets, each rounded up to whole workgroups)")
     print("%-78s %9s %6s %10s %10s %10s" % ("kernel", "grid", "calls", "avg_us", "min_us", "max_us"))
     rows = sorted(groups.items(), key=lambda kv: -sum(kv[1]))
     for (k, g), durs in rows:
@@ -38,7 +39,7 @@ def main():
         b = json.loads(line)
         print("# bench line of the same process: value %.4g %s, ms_per_step %.4f, roofline.kernel %s avg_launch_ms %.4f (HIP events) -- compare with the"
               % (b["value"], b["unit"], b["ms_per_step"], b["roofline"]["kernel"], b["roofline"]["avg_launch_ms"]))
-        print("# rocprofv3 average of that kernel at grid %d above" % (-(-b["roofline"]["units_per_launch"] // 256) * 256))
+        print("# rocprofv3 average of that kernel at the headline's grid above (a population launch: the sum of its parts' grids, each a multiple of 256)")
         kernels = b["roofline"].get("kernels")
         if kernels is None and len(sys.argv) > 3:          # the per-kernel table lives in the side file (bench.py --side-file)
             kernels = json.load(open(sys.argv[3]))["roofline"]["kernels"]
