@@ -255,11 +255,18 @@ int target_batch_step_fused(target_batch_c* b, long n_ticks, double dt, const vo
  * Results equal those of single ticks bit for bit.  While a session is open the records in HBM are stale: any other call on
  * the batch (steps, getters, erase, init) ends the session first.  Needs the automatic layout of the shipped models
  * (axis-separable, packed groups), one (Q, R) class and a batch small enough to be fully resident: ..._live_capacity targets
- * (on an MI355X: 3.1 * 10^5 targets for the linear models, 1.8 to 2.5 * 10^5 fp32 / 4.9 * 10^4 fp64 for the angular ones; a session
- * with the per-tick query or pose output runs a larger kernel: 1.8 to 3.1 * 10^5 fp32).  ..._live_start returns once the resident kernel
+ * (on an MI355X: 3.1 * 10^5 targets for the linear models, 1.8 to 2.5 * 10^5 for the angular ones in either precision -- the fp64
+ * angular kernels park part of the record in LDS; a session with the per-tick query or pose output runs a larger kernel: 1.1 to 3.1 * 10^5;
+ * profiles/r04_live_capacity.txt).  ..._live_start returns once the resident kernel
  * is known to run (its last workgroup says so) and fails after 2 s otherwise; the kernel runs on a high-priority stream of the
  * library's own, so that no stream of the caller shares its hardware queue (work queued behind an endless kernel waits for its end).  Posting faster than the device serves is fine: a wavefront that is behind catches up
- * without polling. */
+ * without polling.
+ * Sessions of one PROCESS share the device: the library counts the resident sessions of the process (all managers) and refuses a
+ * start whose wavefronts do not fit next to the ones already resident ("do not fit the device together") instead of launching a
+ * grid that can only start in part.  A session of ANOTHER process is not seen: there the 2 s start check is what reports it.
+ * While any session of the process is resident, calls that would FREE device memory (a batch that grows, measured-pose rows
+ * switched off, large get_state requests, a destroyed manager) do not call hipFree -- it synchronises the device and would block
+ * until that session ends -- but put the memory on a list that is freed when the last session has left. */
 int target_batch_live_start(target_batch_c* b, double dt, const void* meas_ring_dev, long tick_stride, long ld,
                             const unsigned char* has_ring_dev, long has_stride, long ring_ticks, long first_entry, long max_ticks,
                             double idle_limit_s);
@@ -306,7 +313,9 @@ int target_manager_population_tick(target_manager_c* m);
  * share is launch-bound): one resident kernel per batch, each on a stream of its own so that they are on the device together;
  * per_batch[i] describes batch i's ring as for target_manager_step_sequence_all (ring_ticks > 0); with query != 0 the own-time
  * sphere query of every target runs after every tick inside the resident kernels, into per_batch[i].delta_dev / pose_dev
- * (overwritten every tick), as target_manager_step_sequence_all's fused query does.  The
+ * (overwritten every tick), as target_manager_step_sequence_all's fused query does; like the pose output above they are written
+ * THROUGH the caches before the tick counts as done: copy them on another stream after ..._live_done_all reached tick k and they
+ * hold the results of a tick >= k (exactly k when one tick is posted at a time).  The
  * sessions' wavefronts must fit the device together.  ..._post_all: n_ticks to every batch (one_doorbell_per_tick != 0: as
  * n_ticks separate doorbells); ..._done_all: ticks finished by every wavefront of every batch; ..._stop_all: ticks served. */
 int target_manager_live_start_all(target_manager_c* m, double dt, const target_batch_sequence_c* per_batch, long n_batches, long first_entry,

@@ -329,7 +329,7 @@ struct IntersectArgs {
 // The values: delta (the reference's intersection time, -1 if none) and, if wanted, the pose at that time (identity if none).
 template <class M, typename T>
 __device__ __forceinline__ void sphere_query_values(const T* x, bool own, double t1, double t, const double* origin, double radius,
-                                                    double& delta, double* pose /* [7] or null */) {
+                                                    double& delta, double (&pose)[7], const bool want_pose) {
 #pragma clang fp contract(off)   // fused query, intersect kernel: the same roundings (te_device_math.hpp)
   T pose7[7], twist6[6], acc6[6];
   derive_outputs<M, T>(x, true, own ? (T)0 : (T)(t1 - t), pose7, twist6, acc6);
@@ -344,7 +344,9 @@ __device__ __forceinline__ void sphere_query_values(const T* x, bool own, double
   c[0] = px * px + py * py + pz * pz - radius * radius;
   const double d = first_crossing_quartic(c);   // leftmost real root if >= 0, else -1
   delta = d;
-  if (pose) {
+  // (the array is taken by reference and the choice is a flag: a pointer that may be null made the caller's array escape into
+  // scratch memory -- 64 bytes per lane, and a resident kernel with scratch is also limited by the process's scratch wave slots)
+  if (want_pose) {
     pose[0] = pose[1] = pose[2] = pose[3] = pose[4] = pose[5] = 0; pose[6] = 1;
     if (d > -1) {
       derive_outputs<M, T>(x, true, own ? (T)d : (T)((d + t1) - t), pose7, twist6, acc6);
@@ -358,7 +360,7 @@ template <class M, typename T>
 __device__ __forceinline__ void sphere_query(const T* x, bool own, double t1, double t, const double* origin, double radius,
                                              double* delta_out, double* pose_out /* [7] or null */) {
   double d, out[7];
-  sphere_query_values<M, T>(x, own, t1, t, origin, radius, d, pose_out ? out : nullptr);
+  sphere_query_values<M, T>(x, own, t1, t, origin, radius, d, out, pose_out != nullptr);
   *delta_out = d;
   if (pose_out)
     for (int k = 0; k < 7; ++k) pose_out[k] = out[k];

@@ -604,7 +604,7 @@ __device__ __forceinline__ void sep_step_wave(const StepArgs<T>& a, long wg, con
       // straight to memory (configs[4]'s share: 4.9 -> 10.5 us per tick).  The wavefront's 64 rows are one contiguous run of
       // 3584 bytes, so they go through its LDS and leave as seven full 512-byte stores.
       double qd, qp[7];
-      sphere_query_values<M, T>(xq, true, 0.0, 0.0, a.q_origin, a.q_radius, qd, a.q_pose ? qp : nullptr);
+      sphere_query_values<M, T>(xq, true, 0.0, 0.0, a.q_origin, a.q_radius, qd, qp, a.q_pose != nullptr);
       __hip_atomic_store(reinterpret_cast<unsigned long long*>(&a.q_delta[entry]), (unsigned long long)__double_as_longlong(qd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       if (a.q_pose != nullptr) {
 #pragma unroll

@@ -196,10 +196,10 @@ def render():
 
 def apply(text, blocks):
     for name, body in blocks.items():
-        pat = re.compile(r"(<!-- GENERATED:%s BEGIN[^\n]*-->\n).*?(\n<!-- GENERATED:%s END -->)" % (name, name), re.S)
+        pat = re.compile(r"(<!-- GENERATED:%s BEGIN[^\n]*-->\n).*?(<!-- GENERATED:%s END -->)" % (name, name), re.S)
         if not pat.search(text):
             raise SystemExit("DESIGN.md has no block GENERATED:%s" % name)
-        text = pat.sub(lambda m: m.group(1) + body + m.group(2), text)
+        text = pat.sub(lambda m: m.group(1) + body + "\n" + m.group(2), text)
     return text
 
 
