@@ -326,3 +326,65 @@ def test_ab_ticks_equal_in_place_ticks_bit_for_bit():
         os.unlink(f)
     assert np.isfinite(out[0]).all()
     np.testing.assert_array_equal(out[0], out[1])
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_population_tick_of_four_models_equals_launches_per_batch(models, dtype):
+    """Round 4: one launch steps every batch of a manager (kf_step_population_kernel).  All four motion models, ragged sizes
+    (one of them less than a wavefront), a mask on one batch, eager and recorded, against a second manager stepped batch by
+    batch with single launches: bit for bit; and the oracle on every target of the two smallest batches."""
+    parts = [("angular_rates", 1003), ("angular_velocities", 517), ("uniform_acceleration", 40), ("uniform_velocity", 2050)]
+    ticks, dt = 6, 0.004
+    mgr, batches, out, meas = _build(models, parts, dtype, ticks, dt, 4100)
+    ref, rbatches, _, rmeas = _build(models, parts, dtype, ticks, dt, 4100)
+    assert mgr.population_tick() and ref.population_tick()
+    rng = np.random.default_rng(3)
+    has = [None, torch.as_tensor((rng.random((ticks, parts[1][1])) < 0.7).astype(np.uint8), device="cuda"), None, None]
+    for s in range(ticks):
+        for j, b in enumerate(rbatches):
+            b.step(dt, rmeas[j][s], None if has[j] is None else has[j][s])
+    mgr.step_sequence_all(dt, [m[:3] for m in meas], has_meas=[None if h is None else h[:3] for h in has], use_graph=0)
+    mgr.step_sequence_all(dt, [m[3:] for m in meas], has_meas=[None if h is None else h[3:] for h in has], use_graph=1)
+    torch.cuda.synchronize()
+    for o in out:
+        got, want = mgr.get_state_batch(o["ids"]), ref.get_state_batch(o["ids"])
+        np.testing.assert_array_equal(got[0], want[0])
+        np.testing.assert_array_equal(got[1], want[1])
+    assert mgr.getNumberMeasurements(int(out[1]["ids"][5])) == int(has[1][:, 5].sum())
+    for j in (2, 0):
+        sample = np.arange(parts[j][1])
+        check_state(mgr, out[j]["ids"], _oracle_on_sample(models, out[j], sample, ticks, dt, dtype), dtype, "%s in a population launch" % parts[j][0])
+    ref.close(); mgr.close()
+
+
+def test_population_tick_applies_only_where_every_batch_qualifies(models):
+    """One launch per tick needs at least two non-empty batches, all of them one-class batches in the separable layout with
+    packed groups; anything else keeps a launch per batch (and still gives the same results: the other tests of this file
+    and test_gpu_intersection.py run the dense layouts through the same call)."""
+    dt = 0.004
+    one = np.tile([0, 0, 0, 0, 0, 0, 1.0], (70, 1))
+
+    def manager(names, lanes=0, classes=False):
+        mgr = te.TargetManager(dtype="f64", lanes_per_target=lanes)
+        base = 0
+        for name in names:
+            m = models[name]
+            ids = np.arange(70, dtype=np.uint32) + base
+            base += 70
+            mgr.init_batch(ids, dt, 0.0, one, type=te.MODEL_TYPES[name], Q=m["Q"], R=m["R"], P0=m["P"])
+            if classes:   # a second (Q, R) class in the same batch
+                ids2 = np.arange(30, dtype=np.uint32) + 100_000 + base
+                mgr.init_batch(ids2, dt, 0.0, one[:30], type=te.MODEL_TYPES[name], Q=2.0 * m["Q"], R=m["R"], P0=m["P"])
+        return mgr
+    cases = [(manager(["angular_rates", "angular_velocities"]), True),
+             (manager(["angular_rates"]), False),
+             (manager(["angular_rates", "uniform_acceleration"], lanes=3), False),
+             (manager(["angular_rates", "uniform_velocity"], classes=True), False)]
+    for mgr, want in cases:
+        assert mgr.population_tick() is want
+        mgr.close()
+    keep = manager(["uniform_velocity", "uniform_acceleration"])
+    assert keep.population_tick()
+    keep.set_keep_measurement(True)          # measured-pose rows are written by a kernel behind every batch's step
+    assert not keep.population_tick()
+    keep.close()
