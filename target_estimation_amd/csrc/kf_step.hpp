@@ -499,6 +499,11 @@ kf_step_kernel(const StepArgs<T> a) {
       const int t = i * C::PW + k;
       if (t < C::TRI) EXP_(t) = mem[k];
     }
+    if constexpr (C::TRI_FOLD) {   // the remainder of the triangle rides in the unwrap slots no angle uses (te_layout.hpp)
+#pragma unroll
+      for (int e = 0; e < C::TRI_REM; ++e)
+        if (i == C::fold_lane(e)) EXP_(G * C::PW + e) = mem[C::UW_OFF + C::fold_slot(e)];
+    }
     wave_lds_fence();
     rows_from_lds();
     wave_lds_fence();
@@ -912,6 +917,11 @@ kf_step_kernel(const StepArgs<T> a) {
     }
 #pragma unroll
     for (int w = 0; w < RPL + C::UW; ++w) mem[C::X_OFF + w] = rec[RPL * N + w];
+    if constexpr (C::TRI_FOLD) {   // (after the line above: in these lanes the slot's register image is the stale word it was loaded with)
+#pragma unroll
+      for (int e = 0; e < C::TRI_REM; ++e)
+        if (i == C::fold_lane(e)) mem[C::UW_OFF + C::fold_slot(e)] = EXP_(G * C::PW + e);
+    }
   }
   if (valid) {
     if constexpr ((PK && G > 1) || EKF_SYM) {

@@ -96,7 +96,10 @@ constexpr int sep_min_waves() {
 // the fp64 angular models that is not enough (angular_rates: 57 words = 114 registers of state under an fp64 atan2 / asin chain
 // -> 262, one wavefront per SIMD, 49 152 targets): part of the record is PARKED in the wavefront's LDS between its uses --
 // every lane its own column, word-interleaved (conflict-free ds_read/write_b64), read when its chain's turn comes and written
-// back behind it.  live_park_chains<M, T>() = how many [p v (a)] chains park their covariance words (P) / their state words (x).
+// back behind it.  live_park_p_chains / live_park_x_chains<M, T>() = how many [p v (a)] chains park their covariance words (P) /
+// their state words (x); chosen so that the resident kernels fit three wavefronts per SIMD with at most 13 KB of LDS per
+// wavefront (12 per CU).  -DTE_PARK_P / -DTE_PARK_X override them for experiments (one kernel at a time through
+// tools/kres.py / tools/isa_liveness.py; the library is built without them).
 template <class M, typename T> constexpr int live_park_p_chains() {
 #ifdef TE_PARK_P
   return TE_PARK_P;

@@ -120,7 +120,37 @@ struct Cfg {
     return k;
   }
   static constexpr int TRI = N * (N + 1) / 2;                  // words of the upper triangle
-  static constexpr int PW = SEP ? sep_count() : PK ? (TRI + G - 1) / G : RPL * N;   // words of P per lane in HBM
+  // Packed with G > 1: lane i holds the i-th slice of the triangle.  When TRI is not a multiple of G the slices were rounded
+  // up -- angular_rates on 6 lanes: 29 words for 171 / 6 = 28.5, and with the unwrap slot every lane carries (three of the six
+  // unused) 198 words stored for 192.  Where the unused unwrap slots can take the remainder they do (TRI_FOLD): slices of
+  // TRI / G words, the last TRI % G words of the triangle ride in the spare unwrap slots (fold_lane / fold_slot), the record
+  // is exactly the triangle + x + unwrap memory (and, in fp64, a whole number of 16-byte chunks: no tail row).
+  static constexpr int TRI_REM = (PK && G > 1) ? TRI % G : 0;
+  static constexpr bool uw_slot_used(int lane, int u) {         // does an angle's unwrap word live in (lane, slot u)?  (kf_aux.hpp unwrap_ptr)
+    for (int cc = 0; cc < 3; ++cc)
+      if (M::ANGULAR && (3 + cc) % G == lane && cc / G == u) return true;
+    return false;
+  }
+  static constexpr int uw_spare() {
+    int k = 0;
+    for (int lane = 0; lane < G; ++lane)
+      for (int u = 0; u < UW; ++u) k += uw_slot_used(lane, u) ? 0 : 1;
+    return k;
+  }
+  static constexpr bool TRI_FOLD = PK && G > 1 && TRI_REM > 0 && TRI_REM <= uw_spare();
+  static constexpr int fold_find(int e, bool want_lane) {       // the e-th spare unwrap slot, lanes ascending
+    int k = 0;
+    for (int lane = 0; lane < G; ++lane)
+      for (int u = 0; u < UW; ++u) {
+        if (uw_slot_used(lane, u)) continue;
+        if (k == e) return want_lane ? lane : u;
+        ++k;
+      }
+    return -1;
+  }
+  static constexpr int fold_lane(int e) { return fold_find(e, true); }
+  static constexpr int fold_slot(int e) { return fold_find(e, false); }
+  static constexpr int PW = SEP ? sep_count() : PK ? (TRI_FOLD ? TRI / G : (TRI + G - 1) / G) : RPL * N;   // words of P per lane in HBM
   static constexpr int RW = PW + RPL + UW;                     // record words per lane in HBM
   static constexpr int FRW = RPL * (N + 1) + UW;               // words of the full register image
   static constexpr int VW = 16 / (int)sizeof(T);               // words per 16-byte chunk
@@ -151,12 +181,20 @@ struct Cfg {
         }
       return -1;
     }
-    if (PK) return (r <= c ? tri(r, c) : tri(c, r)) % PW;
+    if (PK) {
+      const int t = r <= c ? tri(r, c) : tri(c, r);
+      if (TRI_FOLD && t >= G * PW) return UW_OFF + fold_slot(t - G * PW);
+      return t % PW;
+    }
     return ((r % K) / G + (r / K) * KPL) * N + c;
   }
   // which of the G lanes of a target holds P(r, c)
   static constexpr int p_lane(int r, int c) {
-    if (PK) return (r <= c ? tri(r, c) : tri(c, r)) / PW;
+    if (PK) {
+      const int t = r <= c ? tri(r, c) : tri(c, r);
+      if (TRI_FOLD && t >= G * PW) return fold_lane(t - G * PW);
+      return t / PW;
+    }
     return r % G;
   }
   // LDS exchange words per target (G > 1 only)

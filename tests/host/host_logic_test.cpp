@@ -45,7 +45,11 @@ void check_layout(const char* name) {
       const int w = C::p_word(r, c);
       CHECK(w == C::PWORD.v[r][c]);
       if (w < 0) { CHECK(C::SEP && group_of(M::TYPE, r) != group_of(M::TYPE, c)); continue; }
-      CHECK(w < C::PW);
+      if (C::TRI_FOLD && w >= C::PW) {   // the remainder of a packed triangle rides in an unwrap slot that no angle uses
+        CHECK(w >= C::UW_OFF && w < C::UW_OFF + C::UW && !C::uw_slot_used(C::p_lane(r, c), w - C::UW_OFF));
+      } else {
+        CHECK(w < C::PW);
+      }
       ++stored;
       if (LAYOUT == LAYOUT_PACKED || LAYOUT == LAYOUT_SEPARABLE_PACKED) {
         CHECK(w == C::p_word(c, r) && C::p_lane(r, c) == C::p_lane(c, r) && C::p_lane(r, c) >= 0 && C::p_lane(r, c) < G);
@@ -58,7 +62,9 @@ void check_layout(const char* name) {
     std::set<std::pair<int, int>> cells;
     for (int r = 0; r < C::N; ++r)
       for (int c = r; c < C::N; ++c) CHECK(cells.insert({C::p_lane(r, c), C::p_word(r, c)}).second);
-    CHECK((int)cells.size() == C::TRI && C::PW * G >= C::TRI && C::PW * G < C::TRI + G);
+    CHECK((int)cells.size() == C::TRI);
+    if (C::TRI_FOLD) CHECK(C::PW * G + C::TRI_REM == C::TRI && C::RW * G == C::TRI + C::N + 3);   // nothing but the triangle, x and the unwrap memory
+    else CHECK(C::PW * G >= C::TRI && C::PW * G < C::TRI + G);
   }
   if (LAYOUT == LAYOUT_SEPARABLE) CHECK(stored == C::PW);
   if (LAYOUT == LAYOUT_SEPARABLE_PACKED) CHECK(stored == 2 * C::PW - C::N);
