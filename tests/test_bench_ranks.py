@@ -179,13 +179,17 @@ def test_two_ranks_end_to_end_on_one_gpu(tmp_path):
     """The literal `bench.py --gpus 2` (it starts its two ranks itself), gloo between them, both on the box's one GPU:
     every rank steps its own shard, rank 0 prints the one line (first) and writes the side file."""
     side = str(tmp_path / "side.json")
-    p, line = _run(["--gpus", "2", "--steps", "8", "--warmup", "2", "--reps", "2", "--workload", "cfg4_64", "--extra-multi", "uv1m_strong",
+    p, line = _run(["--gpus", "2", "--steps", "8", "--warmup", "2", "--reps", "2", "--workload", "cfg4_64", "--extra-multi", "cfg4_1gpu_strong,uv1m_strong",
                     "--extra-steps", "4", "--side-file", side], env={"TE_BENCH_BACKEND": "gloo"}, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["targets_total"] == 2 * line["config"]["targets_per_gpu"]
     assert len(json.dumps(line)) < 4096 and "roofline" in line
+    assert line["roofline"]["kernel"] == "kf_step_population_kernel<double>"       # two models per rank: one launch per tick
     extra = json.load(open(side))["extra"]
-    assert extra[0]["name"] == "uv1m_strong" and extra[0]["targets_per_gpu"] == 500_000
+    # BASELINE configs[3] as stated -- 10^6 targets OVER the ranks, every model split evenly -- comes first
+    assert extra[0]["name"] == "cfg4_1gpu_strong" and extra[0]["targets_per_gpu"] == 500_000 and extra[0]["n_gpus"] == 2
+    assert extra[0]["cycles_per_s"] > extra[0]["targets_per_gpu"] * 2 / (extra[0]["ms_per_step"] * 1e-3) * 0.99    # whole-job rate
+    assert extra[1]["name"] == "uv1m_strong" and extra[1]["targets_per_gpu"] == 500_000
 
 
 @pytest.mark.gpu
