@@ -175,6 +175,60 @@ def rpy_quat(r, p, y):      # only to WRITE test inputs (plain double arithmetic
     return [sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy]
 
 
+def intersection_cases():
+    """Sphere intersection of uniform-acceleration targets straight after their creation (state = [p0 v0 a0] exactly, t1 = t0):
+    the quartic of src/intersection_solver.cpp:58-76, its roots to 50 digits (mpmath.polyroots), the reference's selection rule
+    (Solver::lowestRealRoot, :4-17 with Eigen's smallestRealRoot: the smallest real part among the roots with |imag| < 1e-10; none,
+    or a negative one, or a zero leading coefficient -> -1) and the pose at t1 + delta (uniform_acceleration.cpp:120-131).
+    Cases are kept away from tangency: there a companion-matrix solver in double classifies by its own rounding."""
+    from mpmath import polyroots
+    rng = np.random.default_rng(20240808)
+    origin, radius = np.array([0.25, -0.5, 0.125]), 1.5
+    P, V, A = [], [], []
+    for k in range(48):
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        dist = rng.uniform(2.0, 9.0) if k % 4 else rng.uniform(0.2, 1.2)      # every fourth target starts INSIDE the sphere
+        p = origin + d * dist
+        v = -d * rng.uniform(0.5, 6.0) + rng.normal(0, 0.15, 3)
+        a = rng.normal(0, 0.4, 3) + np.array([0, 0, -0.5])
+        if k % 12 == 5:
+            a = np.zeros(3)                                                    # zero acceleration: "no intersection" in the reference
+        if k % 12 == 7:
+            v = d * rng.uniform(1.0, 4.0); a = d * rng.uniform(0.5, 2.0)       # flying away: no real root >= 0
+        P.append(p); V.append(v); A.append(a)
+    P, V, A = np.array(P), np.array(V), np.array(A)
+    delta, pose, margin = [], [], []
+    for p, v, a in zip(P, V, A):
+        x, y, z = [mpf(float(c)) - mpf(float(o)) for c, o in zip(p, origin)]
+        vx, vy, vz = [mpf(float(c)) for c in v]
+        ax, ay, az = [mpf(float(c)) for c in a]
+        R = mpf(radius)
+        c4 = mpf("0.25") * (ax * ax + ay * ay + az * az)
+        c3 = vx * ax + vy * ay + vz * az
+        c2 = vx * vx + vy * vy + vz * vz + x * ax + y * ay + z * az
+        c1 = 2 * (x * vx + y * vy + z * vz)
+        c0 = x * x + y * y + z * z - R * R
+        if c4 == 0:
+            delta.append(-1.0); pose.append([0, 0, 0, 0, 0, 0, 1.0]); margin.append(1.0)
+            continue
+        roots = polyroots([c4, c3, c2, c1, c0], maxsteps=200, extraprec=200)
+        real = [r.real for r in roots if abs(r.imag) < mpf("1e-10")]
+        # distance from a classification boundary: |imag| of the complex roots, |value| of the smallest real one, gap between real roots
+        m = min([abs(r.imag) for r in roots if abs(r.imag) >= mpf("1e-10")] + [mpf(1)])
+        if real:
+            rs = sorted(real)
+            m = min([m, abs(rs[0])] + [rs[i + 1] - rs[i] for i in range(len(rs) - 1)])
+        margin.append(float(m))
+        dmin = min(real) if real else mpf(-1)
+        if dmin < 0:
+            delta.append(-1.0); pose.append([0, 0, 0, 0, 0, 0, 1.0])
+        else:
+            delta.append(float(dmin))
+            pose.append([float(mpf(float(p[i])) + mpf(float(v[i])) * dmin + mpf("0.5") * mpf(float(a[i])) * dmin * dmin) for i in range(3)] + [0, 0, 0, 1.0])
+    return dict(ix_origin=origin, ix_radius=np.array(radius), ix_p0=P, ix_v0=V, ix_a0=A, ix_delta=np.array(delta), ix_pose=np.array(pose),
+                ix_margin=np.array(margin))
+
+
 def main():
     dt = 1.0 / 250.0
     # one target per model: initial pose, then four ticks: measured, measured, predict only, measured.  The yaw of the
@@ -202,6 +256,9 @@ def main():
         out["x_" + model] = xs
         out["P_" + model] = Ps
         print(model, "x after tick 4:", xs[-1][:6])
+    ix = intersection_cases()
+    out.update(ix)
+    print("intersection cases:", len(ix["ix_delta"]), "hits:", int((ix["ix_delta"] > -1).sum()), "smallest margin to a classification boundary: %.3g" % ix["ix_margin"].min())
     np.savez(os.path.join(HERE, "highprec_kat.npz"), **out)
 
 

@@ -5,7 +5,8 @@ only rounds differently is off by a few ulp amplified by the update's conditioni
 loses three digits).  Bounds, all fp64:
     x:  |dx| <= 1e-13 * max(1, |x|_inf)
     P:  |dP| <= 1e-13 * max|P|  and, entry by entry, |dP_ij| <= 2e-12 * |P_ij| + 1e-13 * sqrt(P_ii P_jj)
-(the measured worst cases are printed by `pytest -s`)."""
+(the measured worst cases are printed by `pytest -s`).  The same fixture holds 48 sphere intersections with the quartic's roots to
+50 digits and the reference's selection rule (further down)."""
 import os
 
 import numpy as np
@@ -82,4 +83,55 @@ def test_hip_path_matches_the_high_precision_answers(kat, name):
         mgr.update(7, dt, kat["meas"][s] if has else None)
         x, P = mgr.get_state_batch([7])
         check("hip %s tick %d" % (name, s + 1), x[0], P[0], kat["x_" + name][s], kat["P_" + name][s])
+    mgr.close()
+
+
+# ---- sphere intersection: quartic roots to 50 digits, the reference's selection rule ---------------------------
+def _ix_check(tag, kat, delta, pose):
+    want_d, want_p = kat["ix_delta"], kat["ix_pose"]
+    hit = want_d > -1
+    assert ((delta > -1) == hit).all(), (tag, np.nonzero((delta > -1) != hit)[0])       # the same targets intersect (indices bit-exact)
+    assert (delta[~hit] == -1).all()
+    rel = np.abs(delta[hit] - want_d[hit]) / want_d[hit]
+    dp = np.abs(pose[hit, :3] - want_p[hit, :3]).max()
+    print("%-28s %d of %d intersect; max rel |d delta| %.2e, max |d position| %.2e" % (tag, hit.sum(), len(hit), rel.max(), dp))
+    assert rel.max() <= 1e-12 and dp <= 1e-12, (tag, rel.max(), dp)
+    np.testing.assert_array_equal(pose[:, 3:], np.tile([0, 0, 0, 1.0], (len(hit), 1)))     # uniform acceleration: identity orientation; misses: the initial pose
+
+
+def test_oracle_intersections_match_the_high_precision_roots(models, kat):
+    m = models["uniform_acceleration"]
+    n = len(kat["ix_delta"])
+    p0 = np.concatenate([kat["ix_p0"], np.tile([0, 0, 0, 1.0], (n, 1))], 1)
+    v0 = np.concatenate([kat["ix_v0"], np.zeros((n, 3))], 1)
+    a0 = np.concatenate([kat["ix_a0"], np.zeros((n, 3))], 1)
+    orc = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], p0, float(kat["dt"]), 0.0, v0, a0)
+    ok, pose, delta = orc.intersection_pose(0.0, kat["ix_origin"], float(kat["ix_radius"]))
+    assert (kat["ix_margin"] > 1e-3).all()            # the cases stay away from where a double-precision solver classifies by rounding
+    assert 12 <= (kat["ix_delta"] > -1).sum() <= 40   # hits and misses both (zero acceleration, flying away, started inside)
+    _ix_check("oracle", kat, delta, pose)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ["one target at a time (the reference's call)", "batched"])
+def test_hip_intersections_match_the_high_precision_roots(models, kat, path):
+    import target_estimation_amd as te
+    m = models["uniform_acceleration"]
+    n = len(kat["ix_delta"])
+    p0 = np.concatenate([kat["ix_p0"], np.tile([0, 0, 0, 1.0], (n, 1))], 1)
+    v0 = np.concatenate([kat["ix_v0"], np.zeros((n, 3))], 1)
+    a0 = np.concatenate([kat["ix_a0"], np.zeros((n, 3))], 1)
+    mgr = te.TargetManager(dtype="f64")
+    ids = np.arange(n, dtype=np.uint32) + 11
+    assert mgr.init_batch(ids, float(kat["dt"]), 0.0, p0, v0, a0, type=m["model"], Q=m["Q"], R=m["R"], P0=m["P"]) == n
+    origin, radius = kat["ix_origin"], float(kat["ix_radius"])
+    if path == "batched":
+        delta, pose, found = mgr.intersect_batch(ids, 0.0, origin, radius)
+        assert found.all()
+    else:
+        delta, pose = np.empty(n), np.empty((n, 7))
+        for i, id_ in enumerate(ids):
+            ok, pose[i], delta[i] = mgr.intersection_pose(int(id_), 0.0, origin, radius)
+            assert mgr.intersection_time(int(id_), 0.0, origin, radius) == delta[i]
+    _ix_check("hip, " + path, kat, delta, pose)
     mgr.close()
