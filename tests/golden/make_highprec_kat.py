@@ -27,6 +27,7 @@ import yaml
 from mpmath import mp, mpf, matrix, sin, cos, atan2, asin, sqrt, floor, pi as mp_pi_f
 
 mp.dps = 50
+AHEAD = 0.0625              # seconds the extrapolating getters look ahead (exact in binary)
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 M_PI = mpf(float(np.pi))    # the reference's M_PI is the double nearest to pi
@@ -129,6 +130,88 @@ def ekf_f(x, dt):           # angular_velocities.cpp:126-140 with geometry.hpp:3
     return out
 
 
+# ---- derived outputs: what updateTargetState leaves in T_, twist_, acceleration_, pose_internal_, and the
+# getters that extrapolate to t1 = t + ahead
+def rpy_to_quat(rpy):       # geometry.hpp:178-189 (x y z w), normalised
+    ph, th, ps = rpy[0] / 2, rpy[1] / 2, rpy[2] / 2
+    w = cos(ph) * cos(th) * cos(ps) + sin(ph) * sin(th) * sin(ps)
+    x = sin(ph) * cos(th) * cos(ps) - cos(ph) * sin(th) * sin(ps)
+    y = cos(ph) * sin(th) * cos(ps) + sin(ph) * cos(th) * sin(ps)
+    z = cos(ph) * cos(th) * sin(ps) - sin(ph) * sin(th) * cos(ps)
+    return normalised([x, y, z, w])
+
+
+def quat_to_rot(q):         # Eigen::Quaterniond::toRotationMatrix
+    x, y, z, w = q
+    return [[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+            [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+            [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]]
+
+
+def rot_to_quat(m):         # Eigen's Matrix3 -> Quaternion (isometryToPose7d, geometry.hpp:590-594): trace branch, else largest diagonal
+    t = m[0][0] + m[1][1] + m[2][2]
+    if t > 0:
+        t = sqrt(t + 1)
+        w = t / 2
+        t = mpf("0.5") / t
+        return [(m[2][1] - m[1][2]) * t, (m[0][2] - m[2][0]) * t, (m[1][0] - m[0][1]) * t, w]
+    i = 0
+    if m[1][1] > m[0][0]:
+        i = 1
+    if m[2][2] > m[i][i]:
+        i = 2
+    j, k = (i + 1) % 3, (i + 2) % 3
+    t = sqrt(m[i][i] - m[j][j] - m[k][k] + 1)
+    q = [mpf(0)] * 4
+    q[i] = t / 2
+    t = mpf("0.5") / t
+    q[3] = (m[k][j] - m[j][k]) * t
+    q[j] = (m[j][i] + m[i][j]) * t
+    q[k] = (m[k][i] + m[i][k]) * t
+    return q
+
+
+def rot_to_rpy(m):          # geometry.hpp:191-196
+    return [atan2(m[2][1], m[2][2]), atan2(-m[2][0], sqrt(m[2][1] * m[2][1] + m[2][2] * m[2][2])), atan2(m[1][0], m[0][0])]
+
+
+def outputs(model, x, ahead):
+    """(pose7, twist6, acc6) at the target's own time, and (pose7, twist6) extrapolated by `ahead` seconds -- updateTargetState and
+    getEstimatedPose / getEstimatedTwist(t1) of src/types/*.cpp."""
+    z3 = [mpf(0)] * 3
+    pos = list(x[0:3])
+    if model == "uniform_velocity":                      # uniform_velocity.cpp:98-140
+        tw, ac = list(x[3:6]) + z3, z3 + z3
+        return (pos + [0, 0, 0, 1], tw, ac), ([pos[i] + tw[i] * ahead for i in range(3)] + [0, 0, 0, 1], tw)
+    if model == "uniform_acceleration":                  # uniform_acceleration.cpp:100-140
+        tw, ac = list(x[3:6]) + z3, list(x[6:9]) + z3
+        return (pos + [0, 0, 0, 1], tw, ac), ([pos[i] + tw[i] * ahead + mpf("0.5") * ac[i] * ahead * ahead for i in range(3)] + [0, 0, 0, 1],
+                                            [tw[i] + ac[i] * ahead for i in range(6)])
+    Rm = quat_to_rot(rpy_to_quat(list(x[3:6])))          # T_.linear()
+    pose7 = pos + rot_to_quat(Rm)
+    rpy_i = rot_to_rpy(Rm)                               # pose_internal_ (isometryToPose6d)
+    if model == "angular_rates":                         # angular_rates.cpp:117-160
+        cr, sr, cp, sp = cos(rpy_i[0]), sin(rpy_i[0]), cos(rpy_i[1]), sin(rpy_i[1])
+        Ear = [[1, 0, -sp], [0, cr, cp * sr], [0, -sr, cp * cr]]     # geometry.hpp:333-352
+        rates = list(x[9:12])
+        tw = list(x[6:9]) + [sum(Ear[i][j] * rates[j] for j in range(3)) for i in range(3)]
+        ac = list(x[12:18])
+        p6 = pos + rpy_i
+        v6 = [p6[i] + tw[i] * ahead + mpf("0.5") * ac[i] * ahead * ahead for i in range(6)]
+        return (pose7, tw, ac), (v6[0:3] + normalised(rpy_to_quat(v6[3:6])), [tw[i] + ac[i] * ahead for i in range(6)])
+    # angular_velocities.cpp:152-184: position advanced by v, the quaternion by Qtran(ahead, omega) (geometry.hpp:493-504)
+    tw, ac = list(x[6:12]), z3 + z3
+    om = tw[3:6]
+    q = rpy_to_quat(rpy_i)
+    on = sqrt(sum(c * c for c in om))
+    if on > 0:
+        half = on * ahead / 2
+        S = [[0, -om[2], om[1], om[0]], [om[2], 0, -om[0], om[1]], [-om[1], om[0], 0, om[2]], [-om[0], -om[1], -om[2], 0]]   # omegaToMatrix: 0.5 * this
+        Qt = [[(cos(half) if i == j else 0) + 2 / on * sin(half) * mpf("0.5") * S[i][j] for j in range(4)] for i in range(4)]
+        q = [sum(Qt[i][j] * q[j] for j in range(4)) for i in range(4)]
+    return (pose7, tw, ac), ([pos[i] + tw[i] * ahead for i in range(3)] + normalised(q), tw)
+
+
 def run(model, Q, R, P0, p0, dt, stream):
     n, m = Q.rows, R.rows
     angular = model in ("angular_rates", "angular_velocities")
@@ -145,7 +228,7 @@ def run(model, Q, R, P0, p0, dt, stream):
     for i in range(m):
         C[i, i] = 1
     I = mp.eye(n)
-    xs, Ps = [], []
+    xs, Ps, outs = [], [], []
     for meas in stream:
         if model == "angular_velocities":
             A = ekf_transition(x, dt)
@@ -167,7 +250,9 @@ def run(model, Q, R, P0, p0, dt, stream):
         x = xp
         xs.append([float(v) for v in x])
         Ps.append([[float(P[i, j]) for j in range(n)] for i in range(n)])
-    return np.array(xs), np.array(Ps)
+        now, later = outputs(model, x, mpf(AHEAD))
+        outs.append([float(v) for v in now[0] + now[1] + now[2] + later[0] + later[1]])    # pose7 twist6 acc6 | pose7 twist6 at t + AHEAD
+    return np.array(xs), np.array(Ps), np.array(outs)
 
 
 def rpy_quat(r, p, y):      # only to WRITE test inputs (plain double arithmetic; the result is the input)
@@ -238,7 +323,7 @@ def main():
               np.array([0.3192, -0.1911, 0.1043] + [0.7 * c for c in rpy_quat(0.12, -0.18, -3.08)]),
               None,
               np.array([0.3391, -0.1832, 0.1077] + [1.1 * c for c in rpy_quat(0.15, -0.16, -2.9)])]
-    out = {"dt": np.array(dt), "p0": p0, "has": np.array([s is not None for s in stream]),
+    out = {"dt": np.array(dt), "ahead": np.array(AHEAD), "p0": p0, "has": np.array([s is not None for s in stream]),
            "meas": np.array([s if s is not None else np.zeros(7) for s in stream])}
     for model in ("uniform_velocity", "uniform_acceleration", "angular_rates", "angular_velocities"):
         y = yaml.safe_load(open(os.path.join(ROOT, "models", "model_%s_params.yaml" % model)))
@@ -252,9 +337,10 @@ def main():
         for i in range(m):
             for j in range(m):
                 R[i, j] = mpf(float(y["R"][i * m + j]))
-        xs, Ps = run(model, Q, R, P0, p0, mpf(dt), stream)
+        xs, Ps, outs = run(model, Q, R, P0, p0, mpf(dt), stream)
         out["x_" + model] = xs
         out["P_" + model] = Ps
+        out["out_" + model] = outs      # [tick][pose7 twist6 acc6 | pose7 twist6 extrapolated by `ahead`]
         print(model, "x after tick 4:", xs[-1][:6])
     ix = intersection_cases()
     out.update(ix)
