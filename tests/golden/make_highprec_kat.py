@@ -342,6 +342,25 @@ def main():
         out["P_" + model] = Ps
         out["out_" + model] = outs      # [tick][pose7 twist6 acc6 | pose7 twist6 extrapolated by `ahead`]
         print(model, "x after tick 4:", xs[-1][:6])
+    # the gimbal branches of quatToRpy (geometry.hpp:156-169, |sin pitch| > 0.9999) through the angular-rates model (linear in rpy;
+    # the EKF's Jacobians are singular there and are not driven through it): pitch +pi/2, then -pi/2, then back to a regular attitude
+    gstream = [np.array([0.31, -0.19, 0.10] + [1.3 * c for c in rpy_quat(0.4, np.pi / 2 - 1e-3, -0.7)]),
+               np.array([0.32, -0.18, 0.11] + [0.9 * c for c in rpy_quat(-0.3, -np.pi / 2 + 2e-3, 0.5)]),
+               np.array([0.33, -0.17, 0.12] + [1.0 * c for c in rpy_quat(0.2, 0.3, 0.9)])]
+    for g in gstream[:2]:
+        q = np.array(g[3:7]) / np.linalg.norm(g[3:7])
+        assert abs(-2 * (q[0] * q[2] - q[3] * q[1])) > 0.9999          # really inside the branch
+    y = yaml.safe_load(open(os.path.join(ROOT, "models", "model_angular_rates_params.yaml")))
+    Q = matrix(18, 18); R = matrix(6, 6); P0 = matrix(18, 18)
+    for i in range(18):
+        for j in range(18):
+            Q[i, j] = mpf(float(y["Q"][i * 18 + j])); P0[i, j] = mpf(float(y["P"][i * 18 + j]))
+    for i in range(6):
+        for j in range(6):
+            R[i, j] = mpf(float(y["R"][i * 6 + j]))
+    xs, Ps, outs = run("angular_rates", Q, R, P0, p0, mpf(dt), gstream)
+    out.update(gimbal_meas=np.array(gstream), gimbal_x=xs, gimbal_P=Ps, gimbal_out=outs)
+    print("gimbal branches: rpy after the three ticks", xs[:, 3:6])
     ix = intersection_cases()
     out.update(ix)
     print("intersection cases:", len(ix["ix_delta"]), "hits:", int((ix["ix_delta"] > -1).sum()), "smallest margin to a classification boundary: %.3g" % ix["ix_margin"].min())

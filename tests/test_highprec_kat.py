@@ -181,3 +181,39 @@ def test_hip_outputs_match_the_high_precision_answers(kat, name):
         assert found.all()
         _out_check("hip %s tick %d at t + %.4f" % (name, s + 1, ahead), (p1[0], t1w[0]), want[19:])
     mgr.close()
+
+
+# ---- the gimbal branches of quatToRpy (geometry.hpp:156-169) -----------------------------------------------------------------------
+def test_oracle_through_the_gimbal_branches(models, kat):
+    """Measured pitch within 1e-3 of +pi/2, then of -pi/2 (|sin pitch| > 0.9999: roll = 0, yaw = 2 atan2(qz, qw)), then a regular
+    attitude, through the angular-rates model: state, covariance and derived outputs against the 50-digit evaluation."""
+    m = models["angular_rates"]
+    dt, ahead = float(kat["dt"]), float(kat["ahead"])
+    t = oracle.OracleTarget(m["model"], m["Q"], m["R"], m["P"], kat["p0"], dt)
+    orc = oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], kat["p0"][None], dt)
+    for s in range(3):
+        t.add_measurement(dt, kat["gimbal_meas"][s])
+        orc.step(dt, kat["gimbal_meas"][s][None])
+        x, P = t.state()
+        check("oracle gimbal tick %d" % (s + 1), x[0], P[0], kat["gimbal_x"][s], kat["gimbal_P"][s])
+        want = kat["gimbal_out"][s]
+        _out_check("oracle gimbal tick %d now" % (s + 1), (orc.pose(), orc.twist(), orc.acceleration()), want[:19])
+        _out_check("oracle gimbal tick %d ahead" % (s + 1), (orc.pose_at((s + 1) * dt + ahead), orc.twist_at((s + 1) * dt + ahead)), want[19:])
+
+
+@pytest.mark.gpu
+def test_hip_through_the_gimbal_branches(kat):
+    import target_estimation_amd as te
+    from conftest import model_path
+    mgr = te.TargetManager(model_path("angular_rates"), dtype="f64")
+    dt, ahead = float(kat["dt"]), float(kat["ahead"])
+    mgr.init(3, dt, 0.0, kat["p0"])
+    for s in range(3):
+        mgr.update(3, dt, kat["gimbal_meas"][s])
+        x, P = mgr.get_state_batch([3])
+        check("hip gimbal tick %d" % (s + 1), x[0], P[0], kat["gimbal_x"][s], kat["gimbal_P"][s])
+        want = kat["gimbal_out"][s]
+        _out_check("hip gimbal tick %d now" % (s + 1), (mgr.getTargetPose(3)[1], mgr.getTargetTwist(3)[1], mgr.getTargetAcceleration(3)[1]), want[:19])
+        p1, t1w, _, _ = mgr.get_est_batch([3], t1=(s + 1) * dt + ahead)
+        _out_check("hip gimbal tick %d ahead" % (s + 1), (p1[0], t1w[0]), want[19:])
+    mgr.close()
