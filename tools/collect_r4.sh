@@ -25,5 +25,6 @@ cp $S/bench_default_kernel_stats.csv profiles/r04_bench_default_kernel_stats.csv
 grep '^{' $S/bench_trace.json > profiles/r04_bench_line_under_kernel_trace.json
 grep '^{' $S/bench_line.json > profiles/r04_bench_line.json
 cp $S/bench_extra.json profiles/r04_bench_extra.json
+cp $S/live_capacity.txt profiles/r04_live_capacity.txt
 python3 tools/design_table.py --write
 du -sh profiles

@@ -15,5 +15,10 @@ echo "trace rc=$?" | tee -a $OUT/progress.txt
 python3 tools/summarize_trace.py $OUT/trace $OUT/bench_trace.json $OUT/bench_extra_trace.json > $OUT/bench_default_rocprofv3.txt 2>> $OUT/progress.txt
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/bench_default_kernel_stats.csv \;
 rm -rf $OUT/trace
-head -70 $OUT/bench_default_rocprofv3.txt | cut -c1-200
+echo "== resident-mode capacity" | tee -a $OUT/progress.txt
+{ echo "# python3 tools/live_capacity.py   -- what the library allows at round 4 (occupancy query incl. static LDS, at most 5 resident wavefronts per SIMD, one per CU in hand)."
+  echo "# Round 3 (profiles/r03_live_capacity.txt): angular_velocities / angular_rates f64 49152 / 49152 plain and with outputs; the other rows as here."
+  python3 tools/live_capacity.py 2>/dev/null | grep -E "^(uniform|angular)"; } > $OUT/live_capacity.txt
+cat $OUT/live_capacity.txt
+head -45 $OUT/bench_default_rocprofv3.txt | cut -c1-200
 du -sh $OUT
