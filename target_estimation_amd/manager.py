@@ -503,8 +503,9 @@ class TargetManager:
         return conv.astype(bool), pose, delta, filt
 
     def step_sequence_all(self, dt, meas, has_meas=None, query=None, use_graph=True, n_ticks=None):
-        """meas: one CUDA tensor [ticks, 7, ld] per batch (batches() order): `ticks` ticks of every batch, the
-        batches' launch chains as concurrent branches of one hipGraph (use_graph) or eagerly.  query =
+        """meas: one CUDA tensor [ticks, 7, ld] per batch (batches() order): `ticks` ticks of every batch -- ONE launch per
+        tick for all of them where population_tick() holds, otherwise a launch per batch (recorded: one graph branch per
+        batch) -- replayed from a recorded hipGraph (use_graph) or eagerly.  query =
         (origin[3], radius, deltas, poses) adds the own-time sphere query of every target after every step;
         deltas[i] [size] and poses[i] [size, 7] (or None) are CUDA double tensors, overwritten every tick."""
         nb = len(meas)          # the library checks it against the number of batches
