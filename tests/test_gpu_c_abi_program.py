@@ -83,3 +83,25 @@ def test_cpp_example_of_the_resident_mode(tmp_path, name, n, steps):
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "live stream example ok" in out.stdout and "%d ticks served" % steps in out.stdout
+
+
+@pytest.mark.parametrize("query", [False, True])
+def test_cpp_example_of_a_mixed_population(tmp_path, query):
+    """examples/mixed_population.cpp: BASELINE configs[3] / configs[4] from plain C++ -- two motion models in one manager, one
+    launch per tick for both (target_manager_population_tick), the fused sphere query, a recorded graph, HIP-event timing."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    libdir = os.path.join(ROOT, "target_estimation_amd", "lib")
+    exe = str(tmp_path / "mixed_population")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-w",
+                           "-I", os.path.join(ROOT, "include", "target_estimation_amd"),
+                           os.path.join(ROOT, "examples", "mixed_population.cpp"), "-o", exe,
+                           "-L", libdir, "-ltarget_estimation_amd", "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe, os.path.join(ROOT, "models"), "6250", "128"] + (["query"] if query else []), capture_output=True, text=True, timeout=300)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "mixed population example ok" in out.stdout and "ONE launch per tick" in out.stdout
+    assert "6250 + 6250 targets" in out.stdout and "256 measurements per target" in out.stdout     # 2 warm-up + 2 timed blocks of 64
+    if query:
+        assert "intersections at the last tick" in out.stdout
