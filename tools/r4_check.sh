@@ -14,6 +14,7 @@ import json, sys
 d = json.load(open(sys.argv[1]))
 print(json.dumps(d["line"])[:700])
 for e in d.get("extra", []):
+    if e.get("name") == "gather_pose": print("  gather_pose: exposed %.3f ms, overlapped %.3f ms" % (e.get("gather_pose_ms_exposed", float("nan")), e.get("gather_pose_ms_overlapped", float("nan")))); continue
     if "error" in e: print("  %-18s ERROR %s" % (e["name"], e["error"][:160]))
     else: print("  %-18s %-3s %9d  %8.2f us/tick  frac %s  %s" % (e["name"], e["dtype"], e["targets_per_gpu"], 1e3 * e["ms_per_step"],
                 ("%.3f" % e["roofline_frac"]) if e.get("roofline_frac") is not None else "  -  ", e["launch_mode"][:50]))
