@@ -335,7 +335,9 @@ class Batch {
   struct Live {
     bool active = false;
     bool zombie = false;             // launched, never seen running, told to stop: synchronise its stream before touching records
-    long long* h_posted = nullptr;   // host-mapped: [0] the doorbell (count | stop bit), [8] (as int) the relay's "done" word
+    char* h_block = nullptr;         // host-mapped block: [0] the doorbell unless it lives behind the BAR, [64] the relay's words
+    long long* bar_bell = nullptr;   // the doorbell in fine-grained DEVICE memory, written by the host through the PCIe BAR (or null)
+    long long* h_posted = nullptr;   // the doorbell as the host writes it (count | stop bit)
     long long* d_posted = nullptr;   // the same block as the device sees it
     int* h_done = nullptr;
     int* d_done = nullptr;
