@@ -298,6 +298,8 @@ class Batch {
   void pin_reserve(long k);
   char* h_pin_ = nullptr;                    // idx int[cap] | dt double[cap] | meas T[7][cap] | has uchar[cap]
   char* d_pin_ = nullptr;                    // the same memory as the device sees it
+  char* bar_pin_ = nullptr;                  // the same sections for flushes of up to one wavefront, in fine-grained device memory behind the PCIe BAR (flush)
+  bool bar_pin_failed_ = false;
   long pin_cap_ = 0;
   // The getter table.  Batches up to kCacheMax build it at the first one-target getter after a change.  A larger batch
   // (up to kCacheBigMax) builds it only for a caller that really sweeps it target by target: the first kBigDirect getters
