@@ -105,3 +105,23 @@ def test_cpp_example_of_a_mixed_population(tmp_path, query):
     assert "6250 + 6250 targets" in out.stdout and "256 measurements per target" in out.stdout     # 2 warm-up + 2 timed blocks of 64
     if query:
         assert "intersections at the last tick" in out.stdout
+
+
+@pytest.mark.parametrize("name,n", [("angular_velocities", 40), ("angular_rates", 700)])
+def test_cpp_example_of_the_realtime_loop(tmp_path, name, n):
+    """examples/realtime_loop.cpp: the reference's node loop without a copy or a launch per tick -- measurements stored through the
+    PCIe BAR into the resident session's ring, poses written by the GPU into host-mapped memory, one doorbell per tick -- and the
+    last poses equal a manager stepped by single launches on the same measurements, bit for bit."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    libdir = os.path.join(ROOT, "target_estimation_amd", "lib")
+    exe = str(tmp_path / "realtime_loop")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-w",
+                           "-I", os.path.join(ROOT, "include", "target_estimation_amd"),
+                           os.path.join(ROOT, "examples", "realtime_loop.cpp"), "-o", exe,
+                           "-L", libdir, "-ltarget_estimation_amd", "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe, model_path(name), str(n), "300"], capture_output=True, text=True, timeout=300)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "realtime loop example ok" in out.stdout and "%d targets, 300 ticks" % n in out.stdout and "measurements-to-poses" in out.stdout
