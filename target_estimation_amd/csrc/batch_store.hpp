@@ -34,6 +34,7 @@ class Batch {
   int n_meas() const { return ops_->L.m; }
   const LayoutInfo& layout() const { return ops_->L; }
   long size() const { return n_; }
+  bool getter_table_is_cheap() const { return n_ <= kCacheMax; }   // (its one-target getters read a host-resident table from the first call after a change)
   size_t elem_size() const { return dtype_ == F64 ? 8 : 4; }
   // Parameter classes: the (Q, R) pairs of the batch's targets (TargetManager::init takes them per target,
   // target_manager.hpp:85-87).  One class: Q, R are shared by every lane (scalar cache / LDS).  Several: a table in

@@ -752,9 +752,37 @@ long long TargetManager::getNumberMeasurements(unsigned id) {
   return 0;
 }
 
+// Node-tick sizes (a few to a thousand targets per call) are a LATENCY path: staging copies and separate launches cost more than
+// the step itself (40 targets: 22 us for the dense host path below, 78 us with the getters behind it).  They go through the
+// one-target queue instead -- host table look-up per id, one indexed launch at the next read, the queue behind the PCIe BAR and the
+// getter table filled by the same launch for up to a wavefront of targets (Batch::flush) -- as a caller looping over the
+// reference's own symbols would, minus the call overhead.  Same results (tests/test_gpu_by_id.py, tests/test_gpu_ingest.py).
+bool TargetManager::smallBatchPath(const unsigned* ids, long n) const {
+  // TE_SMALL_BATCH_QUEUE=<n>: the largest call that takes this path (0 switches it off; the comparison in profiles/)
+  static const long most = [] { const char* e = std::getenv("TE_SMALL_BATCH_QUEUE"); return e && *e ? std::atol(e) : kSmallBatchQueue; }();
+  if (n <= 0 || n > most) return false;
+  for (const auto& b : batches_)
+    if (!b->getter_table_is_cheap()) return false;   // (a batch too large for a host-resident getter table: the bulk paths below)
+  (void)ids;
+  return true;
+}
+
 long TargetManager::updateBatch(const unsigned* ids, long n, double dt, const double* meas, const unsigned char* has_meas) {
   lock_guard<mutex> lg(target_lock_);
   const size_t nb = batches_.size();
+  if (smallBatchPath(ids, n)) {
+    long done = 0;
+    for (long i = 0; i < n; ++i) {
+      Loc loc;
+      if (!find(ids[i], loc)) {
+        if (verbose_) std::cout << "Target(" << ids[i] << ") does not exist!" << std::endl;
+        continue;
+      }
+      batches_[(size_t)loc.batch]->step_one(loc.slot, dt, (meas && (!has_meas || has_meas[i])) ? meas + 7 * i : nullptr);
+      ++done;
+    }
+    return done;
+  }
   // fast path: the caller passes exactly one batch's ids in slot order (the usual case when the same
   // id array is reused every tick): no per-id lookup, dense kernel
   for (size_t b = 0; b < nb; ++b) {
@@ -852,6 +880,18 @@ long TargetManager::getPoseBatch(const unsigned* ids, long n, double* pose, doub
                                  unsigned char* found, bool at_time, double t1) {
   lock_guard<mutex> lg(target_lock_);
   const size_t nb = batches_.size();
+  if (!at_time && smallBatchPath(ids, n)) {   // rows from the host-resident getter table (filled by the flush's own launch)
+    long done = 0;
+    for (long i = 0; i < n; ++i) {
+      Loc loc;
+      const bool ok = find(ids[i], loc);
+      if (found) found[i] = ok ? 1 : 0;
+      if (!ok) continue;
+      batches_[(size_t)loc.batch]->outputs_one(loc.slot, pose ? pose + 7 * i : nullptr, twist ? twist + 6 * i : nullptr, acc ? acc + 6 * i : nullptr, false, 0.0);
+      ++done;
+    }
+    return done;
+  }
   for (size_t b = 0; b < nb; ++b) {   // same fast path as updateBatch
     Batch* bt = batches_[b].get();
     if (bt->size() == n && n > 0 && std::memcmp(ids, bt->slot_ids().data(), sizeof(unsigned) * (size_t)n) == 0) {

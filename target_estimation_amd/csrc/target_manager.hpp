@@ -232,6 +232,8 @@ class TargetManager {
     ResolveCounters* h_counters = nullptr;   // pinned
   } dev_ids_;
   static constexpr long kDevResolveMin = 8192;   // below this the host table is faster than the extra launches
+  static constexpr long kSmallBatchQueue = 1024; // host-array calls of at most this many targets go through the one-target queue (updateBatch)
+  bool smallBatchPath(const unsigned* ids, long n) const;
   void devIdsReserve(long n);
   void devIdsRebuild();
   // loc[e] of every id on the device + the per-batch counts on the host; false: not applicable (too many batches)

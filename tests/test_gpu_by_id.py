@@ -163,3 +163,70 @@ def test_one_target_getters_sweeping_a_large_batch(models):
     sub.step(dt, meas[0][touched]); sub.step(dt, meas[1][touched]); sub.step(dt, meas[2][touched]); sub.step(dt, None); sub.step(dt, None)
     _cmp(mgr, ids[touched], sub, dtype, "one-target updates of a large batch")
     mgr.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_node_tick_sized_calls_by_id(models, dtype):
+    """Calls of up to 1024 ids take the one-target queue (TargetManager::updateBatch's small path): two models in one manager,
+    random order, a subset, unknown ids, masks, an id named twice, predict-only, getters -- against the oracle, target by target."""
+    names = ["angular_velocities", "uniform_acceleration"]
+    N = [70, 45]
+    dt, steps = 0.004, 7
+    rng = np.random.default_rng(11)
+    mgr = te.TargetManager(dtype=dtype)
+    all_ids = rng.permutation(5000)[: sum(N)].astype(np.uint32)
+    parts, base = [], 0
+    for name, n in zip(names, N):
+        m = models[name]
+        p0, meas = synth_stream(name, n, steps + 1, seed=9 + n)
+        ids = all_ids[base:base + n]
+        base += n
+        assert mgr.init_batch(ids, dt, 0.0, p0, type=m["model"], Q=m["Q"], R=m["R"], P0=m["P"]) == n
+        parts.append(dict(name=name, ids=ids, meas=meas, orc=oracle.OracleBatch(m["model"], m["Q"], m["R"], m["P"], p0, dt, dtype=dtype)))
+    ids_all = np.concatenate([p["ids"] for p in parts])
+    owner = np.concatenate([np.full(n, k) for k, n in enumerate(N)])
+    local = np.concatenate([np.arange(n) for n in N])
+    unknown = np.arange(9000, 9007, dtype=np.uint32)
+
+    def oracle_step(g, s, with_meas):
+        p = parts[owner[g]]
+        i = int(local[g])
+        if with_meas:
+            p["orc"]._f("orc_target_add_measurement")(p["orc"]._at(i), float(dt), oracle.oracle._dp(np.ascontiguousarray(p["meas"][s][i])))
+        else:
+            p["orc"]._f("orc_target_update")(p["orc"]._at(i), float(dt))
+
+    for s in range(steps):
+        meas_all = np.concatenate([p["meas"][s] for p in parts])
+        order = rng.permutation(len(ids_all))
+        take = order[: len(order) * 2 // 3] if s % 2 else order
+        if s == 3:
+            take = np.concatenate([take, take[:5]])                      # five ids named twice: two consecutive steps each
+        call_ids = np.concatenate([ids_all[take], unknown])
+        call_meas = np.concatenate([meas_all[take], np.zeros((len(unknown), 7))])
+        mix = rng.permutation(len(call_ids))
+        call_ids, call_meas = call_ids[mix], call_meas[mix]
+        has = (rng.random(len(call_ids)) < 0.7).astype(np.uint8) if s >= 2 else None
+        predict_only = s == 5
+        got = mgr.update_batch(call_ids, dt, None if predict_only else call_meas, None if predict_only else has)
+        assert got == len(take)
+        lut = {int(v): g for g, v in enumerate(ids_all)}
+        for r, v in enumerate(call_ids):
+            if int(v) in lut:
+                oracle_step(lut[int(v)], s, (not predict_only) and (has is None or bool(has[r])))
+        if s % 3 == 2:                                                   # getters between the ticks, unknown ids among them
+            q = np.concatenate([ids_all[rng.permutation(len(ids_all))[:50]], unknown[:3]])
+            rng.shuffle(q)
+            pose, twist, acc, found = mgr.get_est_batch(q)
+            known = np.isin(q, ids_all)
+            np.testing.assert_array_equal(found, known)
+            assert np.isnan(pose[~known]).all()
+            for k, p in enumerate(parts):
+                po, tw = p["orc"].pose(), p["orc"].twist()
+                rows = [r for r, v in enumerate(q) if int(v) in lut and owner[lut[int(v)]] == k]
+                sel = [int(local[lut[int(q[r])]]) for r in rows]
+                np.testing.assert_allclose(pose[rows], po[sel], atol=TOL[dtype]["out_atol"])
+                np.testing.assert_allclose(twist[rows], tw[sel], atol=TOL[dtype]["out_atol"] * 50, rtol=TOL[dtype]["x_rtol"] * 50)
+    for p in parts:
+        _cmp(mgr, p["ids"], p["orc"], dtype, p["name"])
+    mgr.close()

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Latency of the batch extension's host-array calls at node-tick sizes: one target_manager_update_meas_batch (ids + measurements from
+host arrays) followed by one target_manager_get_est_batch (pose + twist + acceleration back to host arrays), for T targets.
+    python tools/batch_call_latency.py          (GPU box)"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import target_estimation_amd as te  # noqa: E402
+
+for model in ("uniform_velocity", "angular_velocities"):
+    for T in (1, 40, 400, 4000):
+        m = te.TargetManager(os.path.join(ROOT, "models", "model_%s_params.yaml" % model))
+        ids = np.arange(T, dtype=np.uint32) + 5
+        p = np.tile([0.1, 0.2, 0.3, 0, 0, 0, 1.0], (T, 1))
+        m.init_batch(ids, 0.004, 0.0, p)
+        reps = 400 if T <= 400 else 100
+        for _ in range(20):
+            m.update_batch(ids, 0.004, p)
+            m.get_est_batch(ids)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            m.update_batch(ids, 0.004, p)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            m.update_batch(ids, 0.004, p)
+            m.get_est_batch(ids)
+        t2 = time.perf_counter()
+        print("%-20s %5d targets: update_meas_batch %7.1f us per call; update_meas_batch + get_est_batch %7.1f us per tick" % (
+            model, T, (t1 - t0) / reps * 1e6, (t2 - t1) / reps * 1e6), flush=True)
+        m.close()
