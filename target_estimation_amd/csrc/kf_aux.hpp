@@ -329,8 +329,17 @@ struct IntersectArgs {
 // The values: delta (the reference's intersection time, -1 if none) and, if wanted, the pose at that time (identity if none).
 template <class M, typename T>
 __device__ __forceinline__ void sphere_query_values(const T* x, bool own, double t1, double t, const double* origin, double radius,
-                                                    double& delta, double (&pose)[7], const bool want_pose) {
+                                                    double& delta, double (&pose)[7], const bool want_pose
+#ifdef TE_QUERY_PHASE_CLOCK
+                                                    , long long* ts = nullptr
+#endif
+                                                    ) {
 #pragma clang fp contract(off)   // fused query, intersect kernel: the same roundings (te_device_math.hpp)
+#ifdef TE_QUERY_PHASE_CLOCK
+#define TE_TS(i) do { if (ts) { __builtin_amdgcn_sched_barrier(0); ts[i] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define TE_TS(i) do {} while (0)
+#endif
   T pose7[7], twist6[6], acc6[6];
   derive_outputs<M, T>(x, true, own ? (T)0 : (T)(t1 - t), pose7, twist6, acc6);
   const double px = (double)pose7[0] - origin[0], py = (double)pose7[1] - origin[1], pz = (double)pose7[2] - origin[2];
@@ -342,7 +351,9 @@ __device__ __forceinline__ void sphere_query_values(const T* x, bool own, double
   c[2] = vx * vx + vy * vy + vz * vz + px * ax + py * ay + pz * az;
   c[1] = 2 * (px * vx + py * vy + pz * vz);
   c[0] = px * px + py * py + pz * pz - radius * radius;
+  TE_TS(1);
   const double d = first_crossing_quartic(c);   // leftmost real root if >= 0, else -1
+  TE_TS(2);
   delta = d;
   // (the array is taken by reference and the choice is a flag: a pointer that may be null made the caller's array escape into
   // scratch memory -- 64 bytes per lane, and a resident kernel with scratch is also limited by the process's scratch wave slots)
@@ -354,6 +365,7 @@ __device__ __forceinline__ void sphere_query_values(const T* x, bool own, double
       for (int k = 0; k < 7; ++k) pose[k] = (double)pose7[k];
     }
   }
+  TE_TS(3);
 }
 
 template <class M, typename T>

@@ -89,7 +89,9 @@ __device__ __forceinline__ void sep_linear_axis(T* x, T (&P)[NB][NB], const T (&
 // had run other kernels before.)
 template <class M, typename T, int LAYOUT, bool PERQR, int LIVE = 0>
 constexpr int sep_min_waves() {
-  return (PERQR && M::TYPE == ANGULAR_RATES && sizeof(T) == 8 && LAYOUT == LAYOUT_SEPARABLE_PACKED) ? 3 : 1;
+  // (the resident uniform-acceleration fp64 kernel with the per-tick query: 170 registers when scheduled freely, 3 wavefronts per SIMD need 168)
+  return ((PERQR && M::TYPE == ANGULAR_RATES && sizeof(T) == 8 && LAYOUT == LAYOUT_SEPARABLE_PACKED) ||
+          (LIVE == 2 && M::TYPE == UNIFORM_ACCELERATION && sizeof(T) == 8)) ? 3 : 1;
 }
 
 // Resident kernels keep the whole record in registers between ticks, and the capacity of the mode is the register file.  For
@@ -156,6 +158,9 @@ __device__ __forceinline__ void sep_step_wave(const StepArgs<T>& a, long wg, con
       return;
     }
   }
+#ifdef TE_QUERY_PHASE_CLOCK
+  const long long ts_begin = (long long)__builtin_readcyclecounter();
+#endif
   if (wg * TPW >= a.n) return;
   const long wave_id = wg;                               // LIVE: index of this wavefront's progress word
   if (a.reverse) wg = (a.n + TPW - 1) / TPW - 1 - wg;   // zig-zag traversal (StepArgs::reverse)
@@ -674,7 +679,21 @@ __device__ __forceinline__ void sep_step_wave(const StepArgs<T>& a, long wg, con
       T xq[N];
 #pragma unroll
       for (int r = 0; r < N; ++r) xq[r] = XW_(r);
-      sphere_query<M, T>(xq, true, 0.0, 0.0, a.q_origin, a.q_radius, &a.q_delta[entry], a.q_pose ? &a.q_pose[entry * 7] : nullptr);
+      double qd, qp[7];
+#ifdef TE_QUERY_PHASE_CLOCK
+      long long ts[8];
+      __builtin_amdgcn_sched_barrier(0); ts[0] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+      sphere_query_values<M, T>(xq, true, 0.0, 0.0, a.q_origin, a.q_radius, qd, qp, a.q_pose != nullptr, ts);
+      // lanes 0..4 of every wavefront report: cycles from the wavefront's first instruction to the head of the query, then the query's phases
+      qd = lane == 0 ? (double)(ts[0] - ts_begin) : lane == 1 ? (double)(ts[1] - ts[0]) : lane == 2 ? (double)(ts[2] - ts[1]) : lane == 3 ? (double)(ts[3] - ts[2]) : qd;
+#else
+      sphere_query_values<M, T>(xq, true, 0.0, 0.0, a.q_origin, a.q_radius, qd, qp, a.q_pose != nullptr);
+#endif
+      a.q_delta[entry] = qd;
+      if (a.q_pose != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) a.q_pose[entry * 7 + k] = qp[k];
+      }
     }
     if constexpr (INDEXED) {
       const long slot = slot_of;

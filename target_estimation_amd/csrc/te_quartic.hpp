@@ -50,6 +50,10 @@ __device__ __forceinline__ float cbrt_f(float x) { return ::cbrtf(x); }
 }}
 #endif
 
+#ifndef TE_QTS
+#define TE_QTS(i)   // phase marks for tools/quartic_bench.hip
+#endif
+
 namespace te {
 #ifdef TE_QUARTIC_HOST
 using namespace qdetail;
@@ -108,10 +112,12 @@ TE_QDEV int cubic_real_roots(double A, double B, double C, double D, double* out
     double dq = fma(q0 + b1, X, c2), q = fma(c2, X, D);
     double t = q * rA;
     const double s = t > 0.0 ? 1.0 : (t < 0.0 ? -1.0 : 0.0);
+    TE_QTS(5);
     double r = cbrt_upper(t);
     t = -dq * rA;
     if (t > 0.0) r = 1.324717957244746 * 1.000001 * fmax(r, sqrt(t));
     double x0 = X - s * r;                                 // outside the outermost root on the side of s
+    TE_QTS(6);
     if (x0 != X) {
       for (int it = 0; it < 80; ++it) {                    // monotone from outside: stops when it no longer advances
         X = x0;
@@ -128,8 +134,10 @@ TE_QDEV int cubic_real_roots(double A, double B, double C, double D, double* out
       }
     }
   }
+  TE_QTS(7);
   double r2[2];
   const int n2 = quadratic_roots(A, b1, c2, r2);
+  TE_QTS(8);
   if (n2 == 0) { out[0] = X; return 1; }
   // merge X into the ascending pair
   if (X <= r2[0]) { out[0] = X; out[1] = r2[0]; out[2] = r2[1]; }
@@ -163,6 +171,106 @@ TE_QDEV double quartic_root_monotone(const double* c, double lo, double hi, bool
   return x;
 }
 
+// How many real roots lie below zero and how many above it?  Sturm's chain of p (leading coefficient > 0) counts them without
+// locating any: p0 = p, p1 = p', p(k+1) = -rem(p(k-1), pk) -- here each multiplied by a positive factor (16 c4, b2^2, e1^2) so
+// that no division is needed:
+//     p2 = b2 x^2 + b1 x + b0,   b2 = 3 c3^2 - 8 c2 c4,  b1 = 2 c2 c3 - 12 c1 c4,  b0 = c1 c3 - 16 c0 c4
+//     p3 = e1 x + e0,            g = 3 c3 b2 - 4 c4 b1,  e1 = 4 c4 b2 b0 + g b1 - 2 c2 b2^2,  e0 = g b0 - c1 b2^2
+//     p4 = -(b2 e0^2 - b1 e0 e1 + b0 e1^2)
+// and (distinct real roots in (a, b]) = V(a) - V(b), V = sign changes along the chain.  A root below zero, or none above it: the
+// answer is -1, which is what most targets get most of the time (a trajectory that misses the sphere, or has left it behind) --
+// some 70 instructions without a branch instead of the critical points' iteration, and a wavefront whose targets are all
+// settled this way skips the rest.  No root below zero and at least one above: the crossing exists and is the smallest positive
+// root, which first_positive_root() finds without the critical points.
+// Every value v is computed next to a magnitude M >= |v| (the same expression over absolute values); its rounding error is at
+// most rho M with rho a small multiple of the unit roundoff that follows from the expression alone (first order; the test uses
+// four times that).  A sign that is not certain -- cancellation, a shortened chain, a multiple root, under- or overflow --
+// settles nothing and the target takes the long road as before.
+//   returns 0: not settled   1: the answer is -1   2: no root below zero, at least one above
+TE_QDEV int quartic_sturm_classify(const double* c) {
+  const double u = 2.220446049250313e-16;
+  const double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4];
+  const double d3 = 4.0 * c4, d2 = 3.0 * c3, d1 = 2.0 * c2;
+  // p2: rho 4 u
+  const double b2b = (8.0 * c4) * c2, b1b = (12.0 * c4) * c1, b0b = (16.0 * c4) * c0;
+  const double b2 = fma(d2, c3, -b2b), Mb2 = fma(fabs(d2), fabs(c3), fabs(b2b));
+  const double b1 = fma(d1, c3, -b1b), Mb1 = fma(fabs(d1), fabs(c3), fabs(b1b));
+  const double b0 = fma(c1, c3, -b0b), Mb0 = fma(fabs(c1), fabs(c3), fabs(b0b));
+  // p3: g rho 7 u, b2^2 rho 9 u, e1 rho 14 u, e0 rho 13 u
+  const double g = fma(d2, b2, -(d3 * b1)), Mg = fma(fabs(d2), Mb2, d3 * Mb1);
+  const double bb = b2 * b2, Mbb = Mb2 * Mb2;
+  const double e1 = fma(d3 * b2, b0, fma(g, b1, -(d1 * bb))), Me1 = fma(d3 * Mb2, Mb0, fma(Mg, Mb1, fabs(d1) * Mbb));
+  const double e0 = fma(g, b0, -(c1 * bb)), Me0 = fma(Mg, Mb0, fabs(c1) * Mbb);
+  // p4: rho 36 u
+  const double p4 = fma(b1 * e0, e1, -fma(b2 * e0, e0, (b0 * e1) * e1));
+  const double Mp4 = fma(Mb1 * Me0, Me1, fma(Mb2 * Me0, Me0, (Mb0 * Me1) * Me1));
+  const double tiny = 1e-280;                               // (below this the relative bounds no longer hold)
+  const bool sure = (fabs(b2) > fma(16.0 * u, Mb2, tiny)) && (fabs(b0) > fma(16.0 * u, Mb0, tiny)) && (fabs(e1) > fma(56.0 * u, Me1, tiny)) &&
+                    (fabs(e0) > fma(52.0 * u, Me0, tiny)) && (fabs(p4) > fma(144.0 * u, Mp4, tiny)) && (c0 != 0.0) && (c1 != 0.0);
+  // (Descartes: with p(0) > 0 and no negative coefficient there is no root at or above zero, whatever lies below)
+  if ((c0 > 0.0) && (c1 >= 0.0) && (c2 >= 0.0) && (c3 >= 0.0)) return 1;
+  if (!sure) return 0;                                      // (NaN and infinities compare false: not sure)
+  const bool sb2 = b2 > 0.0, sb0 = b0 > 0.0, se1 = e1 > 0.0, se0 = e0 > 0.0, sp4 = p4 > 0.0, sc0 = c0 > 0.0, sc1 = c1 > 0.0;
+  // sign sequences: at -inf (+, -, sb2, -se1, sp4); at 0 (sc0, sc1, sb0, se0, sp4); at +inf (+, +, sb2, se1, sp4)
+  const int v_minus = 1 + (int)sb2 + (int)(sb2 == se1) + (int)(se1 == sp4);
+  const int v_zero = (int)(sc0 != sc1) + (int)(sc1 != sb0) + (int)(sb0 != se0) + (int)(se0 != sp4);
+  const int v_plus = (int)(!sb2) + (int)(sb2 != se1) + (int)(se1 != sp4);
+  const int below = v_minus - v_zero, above = v_zero - v_plus;
+  return (below > 0 || above == 0) ? 1 : 2;
+}
+
+// Newton's iteration on a CONVEX piece of p from its left end x, where p(x) > 0: while p' < 0 the tangent's zero lies to the left
+// of the first root of the piece, if there is one, so the iterates never pass it and converge to it; a piece without a root is
+// left through its minimum (p' >= 0) or its right end.  Returns the root, or -1 if the piece holds none (-2: no decision).
+TE_QDEV double quartic_root_convex_from_left(const double* c, double x, double right_end) {
+  for (int it = 0; it < 100; ++it) {
+    double f, df;
+    quartic_eval(c, x, &f, &df);
+    if (!(f > 0.0)) {
+      // at or below zero: converged if that is the rounding noise of p's evaluation (Horner: a few units of roundoff of the
+      // sum of the terms' magnitudes); anything else is not the situation described above
+      const double ax = fabs(x);
+      const double terms = fma(fma(fma(fma(fabs(c[4]), ax, fabs(c[3])), ax, fabs(c[2])), ax, fabs(c[1])), ax, fabs(c[0]));
+      return (-f <= 16.0 * 2.220446049250313e-16 * terms) ? x : -2.0;
+    }
+    if (!(df < 0.0)) return -1.0;
+    const double xn = x - (f * qdetail::rcp(df)) * (1.0 - 1.0e-15);
+    if (!(xn <= right_end)) return -1.0;
+    if (!(xn - x > 4.0 * 2.220446049250313e-16 * fabs(xn))) return xn;
+    x = xn;
+  }
+  return -2.0;
+}
+
+// The smallest positive root of p when p(0) > 0, no root lies below zero and at least one above (quartic_sturm_classify == 2),
+// without the critical points: the inflection points (closed form) cut [0, inf) into at most three pieces of constant convexity.
+// A convex piece that starts above zero is searched from its left end (above); a concave one that starts above zero holds a
+// root only if it ends below zero, and then exactly one.  Returns -2 when rounding leaves no clean decision (the caller falls
+// back on the critical points).
+TE_QDEV double first_positive_root(const double* c) {
+  double infl[2];
+  const int ni = quadratic_roots(6.0 * c[4], 3.0 * c[3], c[2], infl);
+  const double inf = 1.0e308 * 10.0;
+  double a = 0.0;                                           // left end of the current piece; p(a) > 0
+  if (ni == 2 && infl[1] > 0.0) {
+    double f, df;
+    if (infl[0] > 0.0) {                                    // [0, i0] convex
+      quartic_eval(c, infl[0], &f, &df);
+      if (f == 0.0) return -2.0;
+      if (f < 0.0) return quartic_root_monotone(c, 0.0, infl[0], true);
+      const double r = quartic_root_convex_from_left(c, 0.0, infl[0]);
+      if (r != -1.0) return r;
+      a = infl[0];
+    }
+    quartic_eval(c, infl[1], &f, &df);                      // [a, i1] concave
+    if (f == 0.0) return -2.0;
+    if (f < 0.0) return quartic_root_monotone(c, a, infl[1], false);
+    a = infl[1];
+  }
+  const double r = quartic_root_convex_from_left(c, a, inf);   // [a, inf) convex: the root is here
+  return r == -1.0 ? -2.0 : r;
+}
+
 // coefficients lowest order first: c[0] + c[1] x + ... + c[4] x^4.
 // Leftmost real root if it is >= 0, else -1 (also -1 for a zero leading coefficient and for no real root).
 TE_QDEV double first_crossing_quartic(const double* cin) {
@@ -171,9 +279,20 @@ TE_QDEV double first_crossing_quartic(const double* cin) {
   const double sg = cin[4] < 0.0 ? -1.0 : 1.0;             // same roots, leading coefficient > 0
 #pragma unroll
   for (int i = 0; i < 5; ++i) c[i] = sg * cin[i];
+#ifndef TE_QUARTIC_NO_STURM   // (defined: the critical points for every target, as until round 3 -- the comparison in profiles/)
+  const int cls = quartic_sturm_classify(c);
+  TE_QTS(9);
+  if (cls == 1) return -1.0;
+  if (cls == 2) {
+    const double r = first_positive_root(c);
+    if (r >= 0.0) return r;
+  }
+#endif
   // critical points of p, ascending
   double m[3];
+  TE_QTS(0);
   const int k = cubic_real_roots(4.0 * c[4], 3.0 * c[3], 2.0 * c[2], c[1], m);
+  TE_QTS(1);
   double f, df;
   // the first decreasing piece (L, H) with p(L) > 0 > p(H): (-inf, m0) or (m1, m2)
   double L, H;
@@ -192,6 +311,7 @@ TE_QDEV double first_crossing_quartic(const double* cin) {
     if (c[0] == 0.0) return 0.0;
     L = 0.0;
   }
+  TE_QTS(2);
   // inflection points inside (L, H) narrow the piece to constant convexity
   double infl[2];
   const int ni = quadratic_roots(6.0 * c[4], 3.0 * c[3], c[2], infl);
@@ -209,6 +329,7 @@ TE_QDEV double first_crossing_quartic(const double* cin) {
     const double mid = 0.5 * (L + H);
     convex = !(mid > infl[0] && mid < infl[1]);            // p'' < 0 exactly between the inflection points
   }
+  TE_QTS(3);
   return quartic_root_monotone(c, L, H, convex);
 }
 
