@@ -7,8 +7,11 @@
 // (src/intersection_solver.cpp:83), so what the query needs is
 //     first_crossing_quartic(c) = the leftmost real root if it is >= 0, else -1.
 //
-// Eigen finds the roots as eigenvalues of the companion matrix.  Only the leftmost real root matters,
-// and it can be located rigorously from the shape of the curve:
+// Eigen finds the roots as eigenvalues of the companion matrix.  Only the leftmost real root matters.
+// Round 4: most quartics never get as far as a root finder -- Sturm's chain counts the real roots on either side of
+// zero (quartic_sturm_classify below), which settles "-1" for a trajectory that misses the sphere or has left it behind,
+// and tells when the answer is simply the smallest positive root (first_positive_root).  What neither settles
+// (cancellation, multiple roots, exact zeros) is located rigorously from the shape of the curve, as since round 2:
 //   1. the critical points of p (real roots of the cubic p') split the line into monotone pieces.
 //      They come from W. Kahan's cubic algorithm ("To Solve a Real Cubic Equation", 1986): ONE
 //      Newton iteration that starts outside the outermost root and converges monotonically, then
@@ -185,7 +188,8 @@ TE_QDEV double quartic_root_monotone(const double* c, double lo, double hi, bool
 // Every value v is computed next to a magnitude M >= |v| (the same expression over absolute values); its rounding error is at
 // most rho M with rho a small multiple of the unit roundoff that follows from the expression alone (first order; the test uses
 // four times that).  A sign that is not certain -- cancellation, a shortened chain, a multiple root, under- or overflow --
-// settles nothing and the target takes the long road as before.
+// settles nothing and the target takes the long road as before (tools/quartic_bench.hip compares the two roads on recorded
+// quartics, tests/host/quartic_host_test.cpp holds the classification's claims to the oracle's roots).
 //   returns 0: not settled   1: the answer is -1   2: no root below zero, at least one above
 TE_QDEV int quartic_sturm_classify(const double* c) {
   const double u = 2.220446049250313e-16;
