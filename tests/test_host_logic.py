@@ -25,7 +25,8 @@ def test_device_quartic_solver_on_the_host_vs_oracle(tmp_path):
     build = os.path.join(ROOT, "oracle", "_build")
     exe = str(tmp_path / "quartic_host_test")
     src = os.path.join(ROOT, "tests", "host", "quartic_host_test.cpp")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-o", exe, src, "-L", build, "-lte_oracle", "-Wl,-rpath," + build])
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wno-unknown-pragmas", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-o", exe, src, "-L", build, "-lte_oracle", "-Wl,-rpath," + build])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     print(out.stdout[-2000:])
     assert out.returncode == 0, out.stdout[-4000:] + out.stderr
