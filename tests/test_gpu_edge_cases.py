@@ -324,7 +324,8 @@ def _one(orc, i, dt, meas_row):
 def test_getter_table_stays_current(models, name, dtype, lanes):
     """The one-target getters are served from a host table that a flush updates only for the stepped slots:
     after any mix of one-target steps, batch steps, erase (slots move) and re-creation every scalar getter
-    must equal the batch getter, which always runs the outputs kernel on the device.
+    must equal the batch handle's dense getter, which always runs the outputs kernel on the device (and so must the by-id
+    batch getter, served from the same table at this size).
     A flush of up to one wavefront of queued targets writes the table rows from the step kernel itself (one launch, the
     host spins on a completion flag); a longer queue goes through the outputs kernel: the 3-step and the 15-step
     operations below hit both on the lanes-per-target layouts (10 or 21 targets per wavefront) and the first on the
@@ -338,8 +339,18 @@ def test_getter_table_stays_current(models, name, dtype, lanes):
 
     def check():
         arr = np.array(ids, dtype=np.uint32)
-        pose, twist, acc, found = mgr.get_est_batch(arr)
+        # the reference: the outputs kernel on the device over every slot (the batch handle's dense getter), rows brought into the
+        # order of `ids`.  (The by-id batch getter serves calls of this size from the table itself since round 4: it is held to
+        # the same rows below, not used as the reference.)
+        b = mgr.batches()[0]
+        slot_of = {int(v): k for k, v in enumerate(b.slot_ids())}
+        rows = [slot_of[int(v)] for v in ids]
+        pose, twist, acc = (x.cpu().numpy()[rows] for x in b.get_est())
+        pose_b, twist_b, acc_b, found = mgr.get_est_batch(arr)
         assert found.all()
+        np.testing.assert_array_equal(pose_b, pose)
+        np.testing.assert_array_equal(twist_b, twist)
+        np.testing.assert_array_equal(acc_b, acc)
         for j in rng.permutation(len(ids))[:12]:
             for getter, want in ((mgr.getTargetPose, pose), (mgr.getTargetTwist, twist), (mgr.getTargetAcceleration, acc)):
                 ok, got = getter(ids[j])
