@@ -89,9 +89,10 @@ __device__ __forceinline__ void sep_linear_axis(T* x, T (&P)[NB][NB], const T (&
 // had run other kernels before.)
 template <class M, typename T, int LAYOUT, bool PERQR, int LIVE = 0>
 constexpr int sep_min_waves() {
-  // (the resident uniform-acceleration fp64 kernel with the per-tick query: 170 registers when scheduled freely, 3 wavefronts per SIMD need 168)
+  // (the resident uniform-acceleration fp64 and angular-rates fp32 kernels with the per-tick query: 170 / 171 registers when
+  // scheduled freely, 3 wavefronts per SIMD need 168)
   return ((PERQR && M::TYPE == ANGULAR_RATES && sizeof(T) == 8 && LAYOUT == LAYOUT_SEPARABLE_PACKED) ||
-          (LIVE == 2 && M::TYPE == UNIFORM_ACCELERATION && sizeof(T) == 8)) ? 3 : 1;
+          (LIVE == 2 && M::TYPE == UNIFORM_ACCELERATION && sizeof(T) == 8) || (LIVE == 2 && M::TYPE == ANGULAR_RATES && sizeof(T) == 4)) ? 3 : 1;
 }
 
 // Resident kernels keep the whole record in registers between ticks, and the capacity of the mode is the register file.  For

@@ -179,7 +179,7 @@ TE_QDEV double quartic_root_monotone(const double* c, double lo, double hi, bool
 // that no division is needed:
 //     p2 = b2 x^2 + b1 x + b0,   b2 = 3 c3^2 - 8 c2 c4,  b1 = 2 c2 c3 - 12 c1 c4,  b0 = c1 c3 - 16 c0 c4
 //     p3 = e1 x + e0,            g = 3 c3 b2 - 4 c4 b1,  e1 = 4 c4 b2 b0 + g b1 - 2 c2 b2^2,  e0 = g b0 - c1 b2^2
-//     p4 = -(b2 e0^2 - b1 e0 e1 + b0 e1^2)
+//     p4 = -(b2 e0^2 - b1 e0 e1 + b0 e1^2)          (evaluated in a factored form, below)
 // and (distinct real roots in (a, b]) = V(a) - V(b), V = sign changes along the chain.  A root below zero, or none above it: the
 // answer is -1, which is what most targets get most of the time (a trajectory that misses the sphere, or has left it behind) --
 // some 70 instructions without a branch instead of the critical points' iteration, and a wavefront whose targets are all
@@ -193,28 +193,38 @@ TE_QDEV double quartic_root_monotone(const double* c, double lo, double hi, bool
 //   returns 0: not settled   1: the answer is -1   2: no root below zero, at least one above
 TE_QDEV int quartic_sturm_classify(const double* c) {
   const double u = 2.220446049250313e-16;
+  const double tiny = 1e-280;                               // (below this the relative bounds no longer hold)
   const double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4];
+  // (Descartes: with p(0) > 0 and no negative coefficient there is no root at or above zero, whatever lies below)
+  const bool descartes = (c0 > 0.0) && (c1 >= 0.0) && (c2 >= 0.0) && (c3 >= 0.0);
+  const bool sc0 = c0 > 0.0, sc1 = c1 > 0.0;
+  bool sure = (c0 != 0.0) && (c1 != 0.0);
   const double d3 = 4.0 * c4, d2 = 3.0 * c3, d1 = 2.0 * c2;
   // p2: rho 4 u
   const double b2b = (8.0 * c4) * c2, b1b = (12.0 * c4) * c1, b0b = (16.0 * c4) * c0;
   const double b2 = fma(d2, c3, -b2b), Mb2 = fma(fabs(d2), fabs(c3), fabs(b2b));
   const double b1 = fma(d1, c3, -b1b), Mb1 = fma(fabs(d1), fabs(c3), fabs(b1b));
   const double b0 = fma(c1, c3, -b0b), Mb0 = fma(fabs(c1), fabs(c3), fabs(b0b));
+  // p4 = -b2 (e0^2 - e1 h),  h = 4 c4 (b2 (3 c1^2 - 8 c0 c2) - b0^2): the same polynomial with b1 e0 - b0 e1 = b2 h taken out by
+  // hand.  Term by term the leading orders of b1 e0 e1 and b0 e1^2 cancel when the acceleration is small (c4 ~ a^2, c3 ~ a): the
+  // literal form loses |a| / |v| of its digits there and stops being certain below |a| ~ 1e-8; this one does not.
+  // Only the sign of p4 is used: -sign(b2) sign(D), D = e0^2 - e1 h.   rho: h 13 u, D 30 u
+  const double k = fma(3.0 * c1, c1, -(8.0 * c0) * c2), Mk = fma(3.0 * c1, c1, fabs((8.0 * c0) * c2));
+  const double h = d3 * fma(b2, k, -(b0 * b0)), Mh = d3 * fma(Mb2, Mk, Mb0 * Mb0);
+  const bool sb2 = b2 > 0.0, sb0 = b0 > 0.0;
+  sure = sure && (fabs(b2) > fma(16.0 * u, Mb2, tiny)) && (fabs(b0) > fma(16.0 * u, Mb0, tiny));
   // p3: g rho 7 u, b2^2 rho 9 u, e1 rho 14 u, e0 rho 13 u
   const double g = fma(d2, b2, -(d3 * b1)), Mg = fma(fabs(d2), Mb2, d3 * Mb1);
   const double bb = b2 * b2, Mbb = Mb2 * Mb2;
   const double e1 = fma(d3 * b2, b0, fma(g, b1, -(d1 * bb))), Me1 = fma(d3 * Mb2, Mb0, fma(Mg, Mb1, fabs(d1) * Mbb));
   const double e0 = fma(g, b0, -(c1 * bb)), Me0 = fma(Mg, Mb0, fabs(c1) * Mbb);
-  // p4: rho 36 u
-  const double p4 = fma(b1 * e0, e1, -fma(b2 * e0, e0, (b0 * e1) * e1));
-  const double Mp4 = fma(Mb1 * Me0, Me1, fma(Mb2 * Me0, Me0, (Mb0 * Me1) * Me1));
-  const double tiny = 1e-280;                               // (below this the relative bounds no longer hold)
-  const bool sure = (fabs(b2) > fma(16.0 * u, Mb2, tiny)) && (fabs(b0) > fma(16.0 * u, Mb0, tiny)) && (fabs(e1) > fma(56.0 * u, Me1, tiny)) &&
-                    (fabs(e0) > fma(52.0 * u, Me0, tiny)) && (fabs(p4) > fma(144.0 * u, Mp4, tiny)) && (c0 != 0.0) && (c1 != 0.0);
-  // (Descartes: with p(0) > 0 and no negative coefficient there is no root at or above zero, whatever lies below)
-  if ((c0 > 0.0) && (c1 >= 0.0) && (c2 >= 0.0) && (c3 >= 0.0)) return 1;
+  const bool se1 = e1 > 0.0, se0 = e0 > 0.0;
+  sure = sure && (fabs(e1) > fma(56.0 * u, Me1, tiny)) && (fabs(e0) > fma(52.0 * u, Me0, tiny));
+  const double D = fma(e0, e0, -(e1 * h)), MD = fma(Me0, Me0, Me1 * Mh);
+  sure = sure && (fabs(D) > fma(120.0 * u, MD, tiny));
+  if (descartes) return 1;
   if (!sure) return 0;                                      // (NaN and infinities compare false: not sure)
-  const bool sb2 = b2 > 0.0, sb0 = b0 > 0.0, se1 = e1 > 0.0, se0 = e0 > 0.0, sp4 = p4 > 0.0, sc0 = c0 > 0.0, sc1 = c1 > 0.0;
+  const bool sp4 = (D > 0.0) != sb2;
   // sign sequences: at -inf (+, -, sb2, -se1, sp4); at 0 (sc0, sc1, sb0, se0, sp4); at +inf (+, +, sb2, se1, sp4)
   const int v_minus = 1 + (int)sb2 + (int)(sb2 == se1) + (int)(se1 == sp4);
   const int v_zero = (int)(sc0 != sc1) + (int)(sc1 != sb0) + (int)(sb0 != se0) + (int)(se0 != sp4);
