@@ -55,13 +55,16 @@ static void check_grazing(const double* c) {
   }
 }
 
-int main() {
-  std::mt19937_64 g(7);
+// quartic_host_test [seed [size multiplier]]   (the test runs it without arguments: seed 7, multiplier 1)
+int main(int argc, char** argv) {
+  const unsigned long long seed = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 7ull;
+  const long mult = argc > 2 ? std::atol(argv[2]) : 1;
+  std::mt19937_64 g(seed);
   std::normal_distribution<double> N(0, 1);
   std::uniform_real_distribution<double> U(0, 1);
   // sphere scenes, acceleration scale swept over 14 decades (tiny leading coefficients included)
   for (double asc : {1e2, 1.0, 1e-2, 1e-4, 1e-6, 1e-9, 1e-12})
-    for (long i = 0; i < 1500; ++i) {
+    for (long i = 0; i < 1500 * mult; ++i) {
       double p[3], v[3], a[3];
       for (int k = 0; k < 3; ++k) { p[k] = -10 + 20 * U(g); v[k] = 3 * N(g); a[k] = asc * N(g); }
       const double R = 0.5 + 8 * U(g);
@@ -72,7 +75,7 @@ int main() {
     }
   // the shape the fused query meets in BASELINE configs[4] (|p| ~ 10, |v| ~ 0.3, |a| ~ 1e-2 .. 1e-3, R = 1), and grazing
   // trajectories: the closest approach within R (1 +- 1e-3 .. 1e-12) of the sphere, ahead of or behind the target
-  for (long i = 0; i < 20000; ++i) {
+  for (long i = 0; i < 20000 * mult; ++i) {
     double p[3], v[3], a[3];
     const double asc = (i & 1) ? 1e-2 : 1e-3;
     for (int k = 0; k < 3; ++k) { p[k] = 6 * N(g); v[k] = 0.2 * N(g); a[k] = asc * N(g); }
@@ -81,7 +84,7 @@ int main() {
                          v[0] * a[0] + v[1] * a[1] + v[2] * a[2], 0.25 * (a[0] * a[0] + a[1] * a[1] + a[2] * a[2])};
     check(c);
   }
-  for (long i = 0; i < 6000; ++i) {
+  for (long i = 0; i < 6000 * mult; ++i) {
     // straight line through the point n * d (|n| = 1, d = R (1 + eps)) along a direction orthogonal to n, a small acceleration on top
     double n[3], t[3], a[3];
     double nn = 0;
@@ -102,13 +105,13 @@ int main() {
     check_grazing(c);
   }
   // random coefficients over 12 decades, both leading signs
-  for (long i = 0; i < 8000; ++i) {
+  for (long i = 0; i < 8000 * mult; ++i) {
     double c[5];
     for (int k = 0; k < 5; ++k) c[k] = N(g) * std::pow(10.0, -6 + 12 * U(g));
     check(c);
   }
   // prescribed roots (four real / two real + a complex pair / two pairs), well separated
-  for (long i = 0; i < 8000; ++i) {
+  for (long i = 0; i < 8000 * mult; ++i) {
     const double lead = (U(g) < 0.5 ? -1 : 1) * std::pow(10.0, -3 + 6 * U(g));
     double q1[3], q2[3];
     for (double* q : {q1, q2}) {
