@@ -125,3 +125,22 @@ def test_cpp_example_of_the_realtime_loop(tmp_path, name, n):
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "realtime loop example ok" in out.stdout and "%d targets, 300 ticks" % n in out.stdout and "measurements-to-poses" in out.stdout
+
+
+@pytest.mark.parametrize("name,n", [("angular_velocities", 40), ("uniform_acceleration", 300)])
+def test_c_example_of_the_node_tick(tmp_path, name, n):
+    """examples/node_tick.c: the reference node's tick as ONE by-id update call + ONE by-id getter call (the one-target queue and
+    the getter table behind them at this size) equals the ten symbols called target by target on a second manager, bit for bit."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    libdir = os.path.join(ROOT, "target_estimation_amd", "lib")
+    exe = str(tmp_path / "node_tick")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror",
+                           "-I", os.path.join(ROOT, "include", "target_estimation_amd"),
+                           os.path.join(ROOT, "examples", "node_tick.c"), "-o", exe,
+                           "-L", libdir, "-ltarget_estimation_amd", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe, model_path(name), str(n), "200"], capture_output=True, text=True, timeout=300)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "node tick ok" in out.stdout and "largest difference between the two managers' poses: 0;" in out.stdout
