@@ -230,3 +230,25 @@ def test_node_tick_sized_calls_by_id(models, dtype):
     for p in parts:
         _cmp(mgr, p["ids"], p["orc"], dtype, p["name"])
     mgr.close()
+
+
+def _bulk_path_case():
+    """(child process, TE_SMALL_BATCH_QUEUE=0) the node-tick-sized test with the staged bulk paths of the same entry points"""
+    import conftest
+    models = {k: oracle.load_model_yaml(conftest.model_path(k)) for k in conftest.MODEL_FILES}
+    for dtype in ("f64", "f32"):
+        test_node_tick_sized_calls_by_id(models, dtype)
+    print("bulk path ok")
+
+
+def test_node_tick_sized_calls_through_the_bulk_paths():
+    """The same calls with the queue path switched off (TE_SMALL_BATCH_QUEUE=0, read once per process: a child): the host look-up +
+    indexed launch + staged copies that served these sizes until round 4 and still serve managers with a batch of more than
+    16384 targets must give the oracle's answers too."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, TE_SMALL_BATCH_QUEUE="0",
+               PYTHONPATH=os.pathsep.join([os.path.dirname(__file__), os.path.dirname(os.path.dirname(__file__))]))
+    p = subprocess.run([sys.executable, "-c", "import test_gpu_by_id as t; t._bulk_path_case()"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "bulk path ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
