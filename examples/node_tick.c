@@ -4,8 +4,8 @@
  * arrived, update(id, dt) for the others (src/target_manager_ros.cpp:41-64) -- and then reads every target's pose to publish
  * it (:78-87).  With this library the same tick is ONE target_manager_update_meas_batch (ids in any order, a mask for "no
  * measurement this tick") and ONE target_manager_get_est_batch.  At node sizes (up to a thousand ids per call) both go through
- * the one-target queue and the host-resident getter table: one launch per tick -- from C 14.5 us for 40 targets and 30 us for
- * 300 (this program on one MI355X; through the Python binding 23 and 45 us, profiles/r04_batch_call_latency.txt).  The program checks the two-call tick against the reference's own call pattern on a
+ * the one-target queue and the host-resident getter table: one launch per tick -- from C 11 - 14 us for 40 targets, 19 us for
+ * 300, 33 us for 1000 (this program on one MI355X, profiles/r04_fused_flush.txt).  The program checks the two-call tick against the reference's own call pattern on a
  * second manager (the ten symbols, target by target): same poses to the last bit.
  *
  *   gcc -std=c99 -O2 -I include/target_estimation_amd examples/node_tick.c -o node_tick \

@@ -229,6 +229,7 @@ Batch::~Batch() {
   if (h_cache_) (void)hipHostFree(h_cache_);
   device_free(d_state_scratch_);
   if (h_done_) (void)hipHostFree(h_done_);
+  if (d_done_count_) device_free(d_done_count_);
   if (live_.h_block) (void)hipHostFree(live_.h_block);
   device_free(live_.bar_bell);
   device_free(live_.d_block);
@@ -1039,20 +1040,26 @@ void Batch::flush() {
   // spins on it instead of synchronising the stream (tools/launch_latency.hip: the runtime's completion path costs 4 us more
   // than a PCIe write).  Up to one wavefront of queued targets the step kernel itself writes the table rows and the flag --
   // ONE launch per flush; up to one workgroup of the outputs kernel that kernel does.
+  // Round 4: beyond one wavefront of targets (up to kFusedFlushMax) the step kernel still does it all -- its wavefronts count
+  // themselves in and the last one writes the flag (signal_done) -- instead of a second launch and, beyond one workgroup of
+  // the outputs kernel, the runtime's wait (from C, 65 targets: 16.4 -> 12.x us per update + read-back tick; TE_FUSED_FLUSH_MAX).
+  static const long fused_max = [] { const char* e = std::getenv("TE_FUSED_FLUSH_MAX"); return e && *e ? std::atol(e) : kFusedFlushMax; }();
   int seq = 0;
-  if (cache_valid_ && spin_wait_enabled() && k <= std::max<long>(ops_->L.tpw, kOutputsBlock)) {
+  if (cache_valid_ && spin_wait_enabled() && k <= std::max<long>(std::max<long>(ops_->L.tpw, kOutputsBlock), fused_max)) {
     if (!h_done_) {
       TE_HIP_CHECK(hipHostMalloc((void**)&h_done_, 64, hipHostMallocMapped | hipHostMallocCoherent));
       TE_HIP_CHECK(hipHostGetDevicePointer((void**)&d_done_, h_done_, 0));
       *h_done_ = 0;
+      TE_HIP_CHECK(hipMalloc((void**)&d_done_count_, 64));   // the wavefront counter of multi-wavefront flushes: zero between launches
+      TE_HIP_CHECK(hipMemsetAsync(d_done_count_, 0, 64, stream_));
     }
     seq = (int)(++done_seq_ & 0x7fffffffu);   // never 0 (= "no flag"), wraps without overflow
     if (seq == 0) seq = (int)(++done_seq_ & 0x7fffffffu);
   }
-  const bool fused = seq != 0 && k <= ops_->L.tpw;
+  const bool fused = seq != 0 && k <= std::max<long>(ops_->L.tpw, fused_max);
   if (fused) {
     p.o_pose = d_cache_; p.o_twist = d_cache_ + 7 * n_; p.o_acc = d_cache_ + 13 * n_;
-    p.done_flag = d_done_; p.done_seq = seq;
+    p.done_flag = d_done_; p.done_seq = seq; p.done_count = d_done_count_;
   }
   launch_step(p, stream_);
   if (cache_valid_ && !fused) {   // keep the getter table current: only the stepped slots change

@@ -293,9 +293,10 @@ class Batch {
   std::vector<unsigned char> pending_mark_;
   double* d_dtper_ = nullptr;
   // Both live in pinned, device-mapped host memory: the kernels read the queued inputs and write the
-  // outputs there directly, so a flush is two launches and no copies; when the getter table is current and the
-  // queue fits one workgroup the host does not even synchronise the stream but spins on a completion flag the
-  // outputs kernel stores behind its rows (wait_done; tools/launch_latency.hip: 9.4 us instead of 13.3 us of floor).
+  // outputs there directly, so a flush needs no copies; when the getter table is current and the queue holds at most
+  // kFusedFlushMax targets it is ONE launch -- the step kernel writes the stepped rows and then a completion flag -- and the
+  // host does not synchronise the stream but spins on that flag (wait_done; tools/launch_latency.hip: launch + flag 6.7 us
+  // against 13.3 us for two launches and the runtime's wait, which is what longer queues still pay).
   void pin_reserve(long k);
   char* h_pin_ = nullptr;                    // idx int[cap] | dt double[cap] | meas T[7][cap] | has uchar[cap]
   char* d_pin_ = nullptr;                    // the same memory as the device sees it
@@ -325,6 +326,8 @@ class Batch {
   bool cache_valid_ = false;
   int* h_done_ = nullptr;                    // completion flag of the last flush (host-mapped), and its device alias
   int* d_done_ = nullptr;
+  int* d_done_count_ = nullptr;              // device word: wavefronts of a multi-wavefront flush that have written their rows (StepArgs::done_count)
+  static constexpr long kFusedFlushMax = 1024;   // up to this many queued targets the flush is ONE launch (flush)
   unsigned done_seq_ = 0;
   void wait_done(int seq);                   // spin on *h_done_ == seq, falling back to hipStreamSynchronize
   void touch() {                             // call before anything that changes state

@@ -33,12 +33,14 @@ struct StepParams {
   double* q_pose = nullptr;
   int nt_meas = 0;        // nontemporal measurement loads (kf_step.hpp StepArgs::nt_meas)
   int reverse = 0;        // walk the tiles last-to-first (zig-zag between consecutive ticks: kf_step.hpp StepArgs)
-  // indexed launches of at most L.tpw entries: also write the per-slot getter table and a completion flag (StepArgs::o_pose)
+  // indexed launches: also write the per-slot getter table and a completion flag (StepArgs::o_pose); more than L.tpw entries
+  // need done_count (a device word, zero between launches)
   double* o_pose = nullptr;
   double* o_twist = nullptr;
   double* o_acc = nullptr;
   int* done_flag = nullptr;
   int done_seq = 0;
+  int* done_count = nullptr;
   // resident ("live") launch: live_posted != null (kf_step.hpp StepArgs::live_*); n_ticks = the most ticks it will serve
   const long long* live_posted = nullptr;
   long long* live_mirror = nullptr;

@@ -22,7 +22,7 @@ inline StepArgs<T> make_step_args(const StepParams& p) {
   a.q_origin[0] = p.q_origin[0]; a.q_origin[1] = p.q_origin[1]; a.q_origin[2] = p.q_origin[2];
   a.q_radius = p.q_radius; a.q_delta = p.q_delta; a.q_pose = p.q_pose;
   a.reverse = p.reverse; a.nt_meas = p.nt_meas;
-  a.o_pose = p.o_pose; a.o_twist = p.o_twist; a.o_acc = p.o_acc; a.done_flag = p.done_flag; a.done_seq = p.done_seq;
+  a.o_pose = p.o_pose; a.o_twist = p.o_twist; a.o_acc = p.o_acc; a.done_flag = p.done_flag; a.done_seq = p.done_seq; a.done_count = p.done_count;
   a.live_posted = p.live_posted; a.live_mirror = p.live_mirror; a.live_progress = p.live_progress; a.live_done = p.live_done;
   a.live_ring = p.live_ring; a.live_first = p.live_first;
   a.live_spin_limit = p.live_spin_limit; a.live_idle_ticks = p.live_idle_ticks; a.live_flags = p.live_flags; a.live_pose = p.live_pose; a.live_pose_ld = p.live_pose_ld;
@@ -71,8 +71,8 @@ struct OpsImpl {
         throw std::runtime_error("target_estimation_amd: live mode needs the axis-separable layout with packed groups (the automatic choice for the shipped models)");
       }
     }
-    if (p.o_pose && (!p.idx || p.n > C::TPW || !p.o_twist || !p.o_acc || !p.done_flag))
-      throw std::runtime_error("target_estimation_amd: the fused getter table needs an indexed launch of at most one wavefront of entries");
+    if (p.o_pose && (!p.idx || (p.n > C::TPW && !p.done_count) || !p.o_twist || !p.o_acc || !p.done_flag))
+      throw std::runtime_error("target_estimation_amd: the fused getter table needs an indexed launch (and a wavefront counter beyond one wavefront of entries)");
     static const int nt_env = [] { const char* e = std::getenv("TE_NT_MEAS"); return e ? std::atoi(e) : -1; }();
     a.nt_meas = nt_env >= 0 ? nt_env : p.nt_meas;
     if (p.q_delta && (p.idx || p.n_ticks > 1))

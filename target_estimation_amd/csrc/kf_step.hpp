@@ -70,15 +70,17 @@ struct StepArgs {
   // measurements are read once per tick: nt_meas != 0 loads them with the nontemporal policy so that they do not push
   // state out of the Infinity Cache (set for batches large enough to zig-zag; TE_NT_MEAS overrides)
   int nt_meas;
-  // Indexed launches of at most ONE wavefront of entries (the queue of the one-target ABI, Batch::flush): o_pose != null
-  // makes the kernel also write the derived outputs of the stepped slots into the per-slot host table
-  // (pose [.][7], twist [.][6], acceleration [.][6]; what outputs_kernel would write) and then store done_seq to
-  // *done_flag (host-mapped): step, getter table and completion signal in one launch.
+  // Indexed launches of the one-target ABI's queue (Batch::flush): o_pose != null makes the kernel also write the derived
+  // outputs of the stepped slots into the per-slot host table (pose [.][7], twist [.][6], acceleration [.][6]; what
+  // outputs_kernel would write) and then store done_seq to *done_flag (host-mapped): step, getter table and completion signal
+  // in one launch.  More than one wavefront of entries: done_count (a device word, zero between launches) counts the
+  // wavefronts that have written their rows, and the last of the launch's ceil(n / TPW) stores the flag (signal_done).
   double* o_pose;
   double* o_twist;
   double* o_acc;
   int* done_flag;
   int done_seq;
+  int* done_count;
   // RESIDENT ("live") launches of small batches (LIVE variants of the separable kernel; Batch::live_start): the state stays in
   // registers while the kernel waits, tick after tick, for the host to post that the tick's measurements are in the ring.
   // Host memory is touched by ONE wavefront only, the RELAY (the extra, last workgroup of the grid): a store from the GPU to
@@ -334,8 +336,7 @@ __device__ __forceinline__ void store_record(char* tb, int lane, const T* rec) {
 template <typename T> __device__ __forceinline__ T sel3(int c, T a, T b, T d) { return c == 0 ? a : (c == 1 ? b : d); }
 
 // StepArgs::o_pose: the row of the per-slot getter table for one stepped target (outputs_kernel's arithmetic on the same
-// posterior state), then the completion flag.  The launch has one wavefront of entries: once this wave's rows are visible to
-// the host (system-scope fence) lane 0 publishes the sequence number the host spins on.
+// posterior state); the completion flag follows (signal_done).
 template <class M, typename T>
 __device__ __forceinline__ void write_outputs_row(const T* x, long slot, double* o_pose, double* o_twist, double* o_acc) {
   T pose7[7], twist6[6], acc6[6];
@@ -347,16 +348,30 @@ __device__ __forceinline__ void write_outputs_row(const T* x, long slot, double*
 #pragma unroll
   for (int c = 0; c < 6; ++c) o_acc[slot * 6 + c] = (double)acc6[c];
 }
-// ONE wavefront only: the launch has at most TPW entries (kf_ops_impl.hpp refuses o_pose with p.n > C::TPW), so "every row
-// of this launch" = "every lane of this wave".  Each lane makes its own rows visible to the host (system-scope fence), then
-// the lanes meet at a wave barrier -- an explicit ordering of the other lanes' fences before lane 0's store, instead of
-// relying on the wave running in lockstep -- and only then lane 0 publishes the sequence number the host spins on.
-__device__ __forceinline__ void signal_done(int* flag, int seq, int lane) {
+
+// The completion signal of such a launch.  Each lane makes its own rows visible to the host (system-scope fence), then the lanes
+// meet at a wave barrier -- an explicit ordering of the other lanes' fences before lane 0's next step, instead of relying on the
+// wave running in lockstep.  A launch of one wavefront: lane 0 publishes the sequence number the host spins on.  A launch of
+// several: lane 0 counts its wavefront in -- a relaxed add BEHIND the system-scope fence above, which is the release -- and the
+// wavefront that finds itself last (an acquire fence then puts every other wavefront's fence, and so its rows, before what
+// follows) sets the counter back to zero for the next launch and publishes the number.
+__device__ __forceinline__ void signal_done(int* flag, int seq, int lane, int* count, long n_entries, int tpw) {
   __threadfence_system();
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  if (lane == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (lane == 0) {
+    const int total = (int)((n_entries + tpw - 1) / tpw);
+    bool last = true;
+    if (total > 1) {
+      last = __hip_atomic_fetch_add(count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (last) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // QUERY: the own-time sphere query of the target runs after the store, on the posterior state (kf_aux.hpp,
@@ -974,7 +989,7 @@ kf_step_kernel(const StepArgs<T> a) {
           sphere_query<M, T>(xq, true, 0.0, 0.0, a.q_origin, a.q_radius, &a.q_delta[entry], a.q_pose ? &a.q_pose[entry * 7] : nullptr);
       } else {
         if (valid && i == 0) write_outputs_row<M, T>(xq, slot_of, a.o_pose, a.o_twist, a.o_acc);
-        signal_done(a.done_flag, a.done_seq, lane);
+        signal_done(a.done_flag, a.done_seq, lane, a.done_count, a.n, TPW);
       }
     }
   }

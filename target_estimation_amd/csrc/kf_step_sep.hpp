@@ -712,7 +712,7 @@ __device__ __forceinline__ void sep_step_wave(const StepArgs<T>& a, long wg, con
         for (int r = 0; r < N; ++r) xq[r] = XW_(r);
         write_outputs_row<M, T>(xq, slot_of, a.o_pose, a.o_twist, a.o_acc);
       }
-      signal_done(a.done_flag, a.done_seq, lane);
+      signal_done(a.done_flag, a.done_seq, lane, a.done_count, a.n, TPW);
     }
   }
 #undef XW_
